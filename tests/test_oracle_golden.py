@@ -1,0 +1,110 @@
+"""CPU suite: the oracle (oracle/pmx_oracle.c) replayed against every fixture captured from the reference.
+This is what pins the oracle; the GPU parity tests then compare the HIP path with the oracle."""
+import numpy as np
+import pytest
+
+import _golden as G
+from oracle import oracle as O
+
+
+def _check_sub(p, d, t, s, H, tag):
+    pos = np.array([[p.pos[i][0], p.pos[i][1]] for i in range(4)])
+    assert (pos == d["sub_pos"][t, s]).all(), f"{tag} pos"
+    for k, f in (("dir", p.dir), ("pac", p.pac), ("scared", p.scared), ("carry", p.carry), ("ret", p.ret)):
+        assert (np.array(list(f)) == d["sub_" + k][t, s]).all(), f"{tag} {k}"
+    assert (np.array(p.food[:H], np.uint32) == d["sub_food"][t, s]).all(), f"{tag} food"
+    assert (np.array(p.caps[:H], np.uint32) == d["sub_caps"][t, s]).all(), f"{tag} caps"
+    assert p.score == d["sub_score"][t, s], f"{tag} score"
+
+
+def _check_tick(r, d, t, H, tag):
+    for s in range(4):
+        _check_sub(r["sub"][s], d, t, s, H, f"{tag} sub{s}")
+        assert r["subout"][s].score_change == d["sub_schange"][t, s], f"{tag} sub{s} scoreChange"
+        assert r["subout"][s].win == d["sub_win"][t, s], f"{tag} sub{s} _win"
+        assert r["subout"][s].fault == 0
+    assert r["reward"].tobytes() == d["reward"][t].tobytes(), f"{tag} reward {r['reward']} vs {d['reward'][t]}"
+    assert r["done"] == d["done"][t], f"{tag} done"
+    assert (r["legal"] == d["legal"][t]).all(), f"{tag} legal"
+    assert r["score_change"] == d["score_change"][t], f"{tag} score_change"
+    assert (r["obs"] == d["obs"][t].astype(np.float32)).all(), f"{tag} obs"
+
+
+@pytest.mark.parametrize("name", G.names("traj_*.npz"))
+def test_trajectory(name):
+    d, meta = G.load(name)
+    env = O.Env(meta["layout"], meta["length"], meta["legal_reward"], meta["defence"])
+    H = env.L.H
+    init = np.stack([env.obs(i) for i in range(4)])
+    assert (init == d["init_obs"].astype(np.float32)).all()
+    assert [env.legal(i) for i in range(4)] == list(d["init_legal"])
+    for t in range(len(d["actions"])):
+        r = env.tick(d["actions"][t])
+        _check_tick(r, d, t, H, f"{name} t={t}")
+        if d["resets"][t]:
+            env.reset()
+    for t, lists in enumerate(meta["legal_lists_first_ticks"]):
+        pass  # order of the list form is checked in test_legal_list_order
+
+
+def test_legal_list_order():
+    d, meta = G.load("traj_small_uniform.npz")
+    env = O.Env(meta["layout"], meta["length"])
+    for t, lists in enumerate(meta["legal_lists_first_ticks"]):
+        env.tick(d["actions"][t])
+        assert [env.legal_list(i) for i in range(4)] == lists
+
+
+@pytest.mark.parametrize("name", G.names("scen_*.npz"))
+def test_scenarios(name):
+    d, meta = G.load(name)
+    env = O.Env(meta["layout"], meta["length"], meta["legal_reward"], meta["defence"])
+    H = env.L.H
+    for k in range(len(d["actions"])):
+        env.set_state_arrays(d["in_pos"][k], d["in_dir"][k], d["in_pac"][k], d["in_scared"][k], d["in_carry"][k],
+                             d["in_ret"][k], d["in_food"][k], d["in_caps"][k], d["in_score"][k], d["in_steps"][k])
+        r = env.tick(d["actions"][k])
+        _check_tick(r, d, k, H, f"{name} k={k} {meta['names'][k]}")
+
+
+@pytest.mark.parametrize("lay", ["tiny", "small", "blox", "maze23"])
+def test_maze_distances(lay):
+    d, meta = G.load(f"dist_{lay}.npz")
+    cells, dist = O.maze_distances(meta["layout"])
+    assert (cells == d["cells"]).all()
+    assert (dist == d["dist"]).all()
+
+
+def test_gae():
+    d, meta = G.load("gae.npz")
+    for c in meta["cases"]:
+        adv, ret = O.gae(d[c + "_rew"], d[c + "_val"], d[c + "_done"], float(d[c + "_last"]), meta["gamma"], meta["lam"])
+        assert adv.tobytes() == d[c + "_adv"].tobytes(), c
+        assert ret.tobytes() == d[c + "_ret"].tobytes(), c
+
+
+def test_shaping_canonicalize_merge():
+    d, meta = G.load("shaping.npz")
+    tr, _ = G.load(meta["traj"])
+    obs = tr["obs"].astype(np.float32)
+    T = int(d["T"])
+    for t in range(T - 1):
+        for i in range(4):
+            cur = O.canonicalize_obs(obs[t, i]) if i in (0, 2) else obs[t, i]
+            nxt = O.canonicalize_obs(obs[t + 1, i]) if i in (0, 2) else obs[t + 1, i]
+            assert O.shaping(cur, nxt) == d["shaping"][t, i], (t, i)
+    for j, t in enumerate(d["ticks"]):
+        for i in range(4):
+            assert (O.canonicalize_obs(obs[t, i]) == d["canon_red"][j, i]).all()
+        assert (O.merge_obs(obs[t, 1], obs[t, 3]) == d["merged_blue"][j]).all()
+        assert (O.merge_obs(O.canonicalize_obs(obs[t, 0]), O.canonicalize_obs(obs[t, 2])) == d["merged_red"][j]).all()
+
+
+def test_dump_order_prefix():
+    """SURVEY appendix A lists the first visited offsets of the reference BFS."""
+    o = O.dump_order(3)
+    want = [(0, 0), (-1, -1), (-1, 0), (-1, 1), (0, -1), (0, 1), (1, -1), (1, 0), (1, 1), (-2, -2), (-2, -1), (-2, 0),
+            (-1, -2), (0, -2), (-2, 1), (-2, 2), (-1, 2), (0, 2), (1, -2), (1, 2), (2, -2), (2, -1), (2, 0), (2, 1),
+            (2, 2), (-3, -3)]
+    assert [tuple(x) for x in o[:len(want)]] == want
+    assert len(o) == 49 and len({tuple(x) for x in o}) == 49
