@@ -1,0 +1,153 @@
+/*
+ * pmx.h -- C ABI of the MI355X-native Pac-Man Capture-the-Flag environment step.
+ *
+ * The reference (ceselder/pacman-marl-2025) is plain Python and has no FFI of its own; the boundary it
+ * offers for this path is the call surface of gymPacMan.gymPacMan_parallel_env (gymPacMan.py:15-270) and
+ * the CaptureAgent action API (captureAgents.py:91-162).  This header is the C ABI a maintainer would bind
+ * UNDER those Python classes (ctypes stub in INTEGRATION.md); each entry point cites what it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative PMX_ERR_* code; pmx_last_error() returns a
+ *     thread-local description of the last failure.  No exceptions cross the boundary.
+ *   - the caller owns every buffer; the library owns only the opaque pmx_env handle (and the device
+ *     memory behind it).  Pointers named *_dev are DEVICE pointers (HIP), everything else is host memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All *_dev work is
+ *     stream-ordered and asynchronous; the library never synchronises unless the comment says so.
+ *   - a handle is bound to one device and is not thread-safe.
+ *   - coordinates: (x, y), origin bottom-left; bit x of row word y (game.py:162-167, layout.py:108-112).
+ *   - actions / directions: 0 North, 1 East, 2 South, 3 West, 4 Stop (gymPacMan.py:66-89).
+ *   - agents 0,2 are red and start on the left half, agents 1,3 are blue (capture.py:316-319,
+ *     gymPacMan.py:150,185,210); pmx_create rejects layouts where that does not hold.
+ */
+#ifndef PMX_H
+#define PMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMX_VERSION 1
+#define PMX_MAX_DIM 32      /* width and height <= 32: one uint32 per board row */
+#define PMX_MAX_CAPSULES 4
+
+enum {
+    PMX_OK = 0,
+    PMX_ERR_INVALID = -1,       /* bad argument / malformed layout */
+    PMX_ERR_UNSUPPORTED = -2,   /* valid request this build does not implement */
+    PMX_ERR_HIP = -3,           /* a HIP runtime call failed (message has the HIP error string) */
+    PMX_ERR_NOMEM = -4
+};
+
+enum { PMX_OBS_F32 = 0, PMX_OBS_BF16 = 1, PMX_OBS_U8 = 2 };
+
+typedef struct pmx_env pmx_env;
+
+/* What gymPacMan_parallel_env.__init__ takes (gymPacMan.py:15) plus the batch size.  The .lay text is parsed
+ * by the host language (layout.py:95-130); rows arrive bottom-up as bit masks. */
+typedef struct {
+    int32_t width, height;
+    const uint32_t *wall_rows;   /* [height] '%' cells */
+    const uint32_t *food_rows;   /* [height] '.' cells */
+    const uint32_t *cap_rows;    /* [height] 'o' cells (at most PMX_MAX_CAPSULES bits) */
+    const int8_t *starts;        /* [4][2] (x, y) of layout digits 1..4 = agents 0..3 (layout.py:113-114,128-129) */
+    int32_t n_envs;              /* independent games advanced in lock-step */
+    int32_t length;              /* `length` (gymPacMan.py:55): an episode lasts length+1 ticks (gymPacMan.py:268) */
+    int32_t legal_reward;        /* reward_forLegalAction (gymPacMan.py:254-257) */
+    int32_t defence_reward;      /* defenceReward (gymPacMan.py:238-242) */
+    int32_t auto_reset;          /* 1: an env that terminates is reset inside the step, the way the reference's
+                                    caller does right after a done (pacman_mappo_resnet.py:528-538); the
+                                    observations/legal masks returned for it are those of the fresh game */
+    int32_t obs_dtype;           /* PMX_OBS_*: element type of the observation planes (reference: float32) */
+    int32_t obs_agents;          /* bit i set = emit agent i's observation; 0 means all four (0xF) */
+    int32_t device;              /* HIP device ordinal */
+} pmx_config;
+
+/* Outputs of one tick = what gymPacMan.step returns (gymPacMan.py:191-193), batched.  Any pointer may be
+ * NULL to skip that output. */
+typedef struct {
+    void *obs_dev;               /* [n_envs][n_emit][8][H][W] obs_dtype; n_emit = popcount(obs_agents), agents in
+                                    increasing index order.  Agent i's planes are encoded right after agent i's own
+                                    sub-step (gymPacMan.py:166-167) */
+    double *reward_dev;          /* [n_envs][2] team reward (red, blue) as float64, summed in the reference's order */
+    uint8_t *done_dev;           /* [n_envs] terminations (gymPacMan.py:261-270) */
+    uint8_t *legal_dev;          /* [n_envs][4] bit a = action a legal in the state the caller acts on next */
+    int32_t *score_change_dev;   /* [n_envs] info['score_change'] */
+    int32_t *score_dev;          /* [n_envs] game.state.data.score after the tick, BEFORE any auto-reset
+                                    (pacman_mappo_resnet.py:529 reads it at a done) */
+} pmx_step_out;
+
+/* Dynamic part of one game = the fields of capture.GameState / game.AgentState that the path reads
+ * (game.py:120-131,374-396).  Used by pmx_get_state / pmx_set_state, fixtures and the GameState facade. */
+typedef struct {
+    int8_t pos[4][2];
+    int8_t dir[4];               /* configuration.direction */
+    uint8_t pac[4];              /* isPacman */
+    uint8_t scared[4];           /* scaredTimer */
+    uint16_t carry[4];           /* numCarrying */
+    uint16_t ret[4];             /* numReturned */
+    uint32_t food[PMX_MAX_DIM];
+    uint32_t caps[PMX_MAX_DIM];
+    int32_t score;
+    int32_t steps;               /* gymPacMan_parallel_env.steps */
+} pmx_state;
+
+int pmx_version(void);
+const char *pmx_last_error(void);
+
+/* gymPacMan_parallel_env.__init__ (gymPacMan.py:15-89) + CaptureRules.newGame (capture.py:369-382): validates the
+ * layout, allocates device state for n_envs games and puts every game in its initial state. */
+int pmx_create(const pmx_config *cfg, pmx_env **out);
+int pmx_destroy(pmx_env *env);
+
+/* shape helpers for the binding */
+int pmx_obs_shape(const pmx_env *env, int32_t *n_emit, int32_t *height, int32_t *width, int32_t *elem_bytes);
+
+/* gymPacMan_parallel_env.reset (gymPacMan.py:92-141).  mask_dev: [n_envs] non-zero = reset that env; NULL = all.
+ * out (may be NULL): obs_dev / legal_dev are filled for ALL envs from their current state (the four agents see
+ * the same state, gymPacMan.py:135-137); the other members are ignored. */
+int pmx_reset(pmx_env *env, const uint8_t *mask_dev, const pmx_step_out *out, void *stream);
+
+/* gymPacMan_parallel_env.step with self_play=True (gymPacMan.py:143-193): actions_dev [n_envs][4] int8, one
+ * requested action per agent; an illegal or out-of-range action becomes Stop (capture.py:473-474). */
+int pmx_step(pmx_env *env, const int8_t *actions_dev, const pmx_step_out *out, void *stream);
+
+/* One agent's sub-step of the same tick (the body of the loop gymPacMan.py:149-169), so that host-side
+ * CaptureAgent bots can choose on the mid-tick state (gymPacMan.py:157).  Call with agent = 0,1,2,3 in this
+ * order; actions_dev [n_envs] int8.  out->obs_dev, if set, receives [n_envs][8][H][W] for this agent.  The
+ * call with agent == 3 closes the tick: reward/done/legal/score_change/score are written then (and only then),
+ * and auto-reset, if configured, is applied. */
+int pmx_step_agent(pmx_env *env, int agent, const int8_t *actions_dev, const pmx_step_out *out, void *stream);
+
+/* Observation planes / legal masks of the CURRENT state for all emitted agents (gymPacMan.get_Observation,
+ * gymPacMan.py:195-229; GameState.getLegalActions, capture.py:101-105). */
+int pmx_observe(pmx_env *env, void *obs_dev, uint8_t *legal_dev, void *stream);
+
+/* Host copies of `count` games starting at `first`.  These two calls synchronise the stream. */
+int pmx_get_state(pmx_env *env, int32_t first, int32_t count, pmx_state *states, void *stream);
+int pmx_set_state(pmx_env *env, int32_t first, int32_t count, const pmx_state *states, void *stream);
+
+/* distanceCalculator.computeDistances (distanceCalculator.py:111-150) for the env's layout.  cells_dev
+ * [n_cells][2] int8 receives the open cells in Grid.asList(False) order (game.py:225-230), dist_dev
+ * [n_cells][n_cells] uint8 the shortest 4-neighbour path lengths (255 = unreachable).  *n_cells is a host
+ * output available on return (the count is computed on the host); dist_dev may be NULL to query it. */
+int pmx_maze_distances(pmx_env *env, int8_t *cells_dev, uint8_t *dist_dev, int32_t *n_cells, void *stream);
+
+/* pacman_mappo_resnet.compute_gae (pacman_mappo_resnet.py:277-290) for n independent series laid out
+ * [T][n] (time-major): rewards/values/dones float32, last_value [n] float32; adv/ret [T][n] float32. */
+int pmx_gae(const float *rewards_dev, const float *values_dev, const float *dones_dev, const float *last_value_dev,
+            int32_t T, int32_t n, double gamma, double lam, float *adv_dev, float *ret_dev, void *stream);
+
+/* Training-side observation post-processing on [n][8][H][W] blocks of obs_dtype elements
+ * (pacman_mappo_resnet.py:215-229 canonicalize_obs for a red learner, :267-274 merge_obs_for_critic). */
+int pmx_canonicalize_obs(const void *in_dev, void *out_dev, int32_t n, int32_t H, int32_t W, int32_t obs_dtype,
+                         void *stream);
+int pmx_merge_obs(const void *a_dev, const void *b_dev, void *out_dev, int32_t n, int32_t H, int32_t W,
+                  int32_t obs_dtype, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMX_H */

@@ -1,0 +1,95 @@
+"""ctypes binding of the C ABI in include/pmx.h (libpmx_hip.so).
+
+There is no CPU fallback: if the HIP library is missing or does not load, importing the product fails loudly."""
+import ctypes as C
+import os
+
+from . import build as _build
+
+PMX_MAX_DIM = 32
+OBS_F32, OBS_BF16, OBS_U8 = 0, 1, 2
+
+
+class PmxError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32),
+                ("wall_rows", C.POINTER(C.c_uint32)), ("food_rows", C.POINTER(C.c_uint32)),
+                ("cap_rows", C.POINTER(C.c_uint32)), ("starts", C.POINTER(C.c_int8)),
+                ("n_envs", C.c_int32), ("length", C.c_int32), ("legal_reward", C.c_int32),
+                ("defence_reward", C.c_int32), ("auto_reset", C.c_int32), ("obs_dtype", C.c_int32),
+                ("obs_agents", C.c_int32), ("device", C.c_int32)]
+
+
+class StepOut(C.Structure):
+    _fields_ = [("obs_dev", C.c_void_p), ("reward_dev", C.c_void_p), ("done_dev", C.c_void_p),
+                ("legal_dev", C.c_void_p), ("score_change_dev", C.c_void_p), ("score_dev", C.c_void_p)]
+
+
+class State(C.Structure):
+    _fields_ = [("pos", (C.c_int8 * 2) * 4), ("dir", C.c_int8 * 4), ("pac", C.c_uint8 * 4), ("scared", C.c_uint8 * 4),
+                ("carry", C.c_uint16 * 4), ("ret", C.c_uint16 * 4), ("food", C.c_uint32 * PMX_MAX_DIM),
+                ("caps", C.c_uint32 * PMX_MAX_DIM), ("score", C.c_int32), ("steps", C.c_int32)]
+
+
+# every symbol include/pmx.h declares: (name, restype, argtypes)
+_VP, _I32 = C.c_void_p, C.c_int32
+PROTOTYPES = [
+    ("pmx_version", C.c_int, []),
+    ("pmx_last_error", C.c_char_p, []),
+    ("pmx_create", C.c_int, [C.POINTER(Config), C.POINTER(_VP)]),
+    ("pmx_destroy", C.c_int, [_VP]),
+    ("pmx_obs_shape", C.c_int, [_VP, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
+    ("pmx_reset", C.c_int, [_VP, _VP, C.POINTER(StepOut), _VP]),
+    ("pmx_step", C.c_int, [_VP, _VP, C.POINTER(StepOut), _VP]),
+    ("pmx_step_agent", C.c_int, [_VP, C.c_int, _VP, C.POINTER(StepOut), _VP]),
+    ("pmx_observe", C.c_int, [_VP, _VP, _VP, _VP]),
+    ("pmx_get_state", C.c_int, [_VP, _I32, _I32, C.POINTER(State), _VP]),
+    ("pmx_set_state", C.c_int, [_VP, _I32, _I32, C.POINTER(State), _VP]),
+    ("pmx_maze_distances", C.c_int, [_VP, _VP, _VP, C.POINTER(_I32), _VP]),
+    ("pmx_gae", C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, C.c_double, C.c_double, _VP, _VP, _VP]),
+    ("pmx_canonicalize_obs", C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _VP]),
+    ("pmx_merge_obs", C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
+]
+# test / bench hooks that are not part of the public header
+EXTRA = [
+    ("pmx_gae_mode", C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, C.c_double, C.c_double, _VP, _VP, C.c_int, _VP]),
+]
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Load libpmx_hip.so (building it first if the sources are newer and hipcc is available)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path) or _build.stale():
+        try:
+            _build.build()
+        except Exception as e:  # no compiler on this machine: use the prebuilt file if there is one
+            if not os.path.exists(path):
+                raise PmxError(f"libpmx_hip.so is missing and could not be built ({e}); run "
+                               f"`python -c 'import __graft_entry__ as g; g.build()'` on a machine with hipcc") from e
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:
+        raise PmxError(f"cannot load {path}: {e} (the product has no CPU fallback)") from e
+    for name, res, args in PROTOTYPES + EXTRA:
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().pmx_last_error()
+        raise PmxError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")

@@ -1,0 +1,399 @@
+// pmx_api.hip -- the C ABI of include/pmx.h on top of the HIP kernels (gfx950).
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/pmx.h"
+#include "pmx_device.h"
+
+extern "C" hipError_t pmx_launch_rule(const PmxTickParams *p, int H, hipStream_t st);
+extern "C" hipError_t pmx_launch_rule_agent(const PmxTickParams *p, int H, int agent, hipStream_t st);
+extern "C" hipError_t pmx_launch_reset(const PmxTickParams *p, int H, hipStream_t st);
+extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, int dtype, hipStream_t st);
+extern "C" hipError_t pmx_launch_maze(const PmxLayoutDev *lay_dev, const int16_t *cell_index_dev, int n_cells,
+                                      const int8_t *cells_dev, uint8_t *dist_dev, hipStream_t st);
+
+struct pmx_env {
+    pmx_config cfg;
+    PmxLayoutDev lay;          // host copy
+    PmxLayoutDev *lay_dev;
+    int8_t *dump_dev;
+    uint32_t *state_dev;
+    uint32_t *snap_dev;
+    int n_emit;
+    int emit[4];
+    int elem_bytes;
+    int open_agent;            // next agent expected by pmx_step_agent
+    std::vector<int8_t> cells; // open cells in asList(False) order
+    std::vector<int16_t> cell_index;
+};
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(PMX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));    \
+    } while (0)
+
+// Order in which the FIFO BFS of dumpFoodFromDeath (capture.py:635-661) first visits offsets from the death
+// cell: start (0,0); pop; skip if seen; expand the 3x3 neighbourhood with dx outer, dy inner.
+std::vector<int8_t> dump_order(int R)
+{
+    const int span = 2 * R + 1;
+    std::vector<uint8_t> seen((size_t)span * span, 0);
+    std::vector<std::pair<int, int>> q;
+    q.reserve((size_t)span * span * 9 + 1);
+    q.emplace_back(0, 0);
+    std::vector<int8_t> out;
+    for (size_t head = 0; head < q.size(); ++head) {
+        auto [x, y] = q[head];
+        uint8_t &s = seen[(size_t)(x + R) * span + (y + R)];
+        if (s) continue;
+        s = 1;
+        out.push_back((int8_t)x);
+        out.push_back((int8_t)y);
+        for (int dx = -1; dx <= 1; ++dx)
+            for (int dy = -1; dy <= 1; ++dy) {
+                int nx = x + dx, ny = y + dy;
+                if (std::abs(nx) > R || std::abs(ny) > R) continue;
+                q.emplace_back(nx, ny);
+            }
+    }
+    return out;
+}
+
+hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+void fill_tick_params(pmx_env *env, PmxTickParams &p, const int8_t *actions, const pmx_step_out *out)
+{
+    std::memset(&p, 0, sizeof(p));
+    p.state = env->state_dev;
+    p.snap = env->snap_dev;
+    p.lay = env->lay_dev;
+    p.dump = env->dump_dev;
+    p.actions = actions;
+    p.N = env->cfg.n_envs;
+    p.length = env->cfg.length;
+    p.legal_reward = env->cfg.legal_reward;
+    p.defence_reward = env->cfg.defence_reward;
+    p.auto_reset = env->cfg.auto_reset;
+    if (out) {
+        p.reward = out->reward_dev;
+        p.done = out->done_dev;
+        p.legal = out->legal_dev;
+        p.score_change = out->score_change_dev;
+        p.score = out->score_dev;
+    }
+}
+
+int launch_expand(pmx_env *env, void *obs, bool from_snapshots, int single_agent, hipStream_t st)
+{
+    PmxExpandParams x;
+    std::memset(&x, 0, sizeof(x));
+    const size_t snap_sz = (size_t)PMX_SNAP_WORDS(env->lay.H) * env->cfg.n_envs;
+    for (int a = 0; a < 4; ++a)
+        x.snap[a] = (from_snapshots && a < 3) ? env->snap_dev + a * snap_sz : env->state_dev;
+    x.lay = env->lay_dev;
+    x.obs = obs;
+    x.N = env->cfg.n_envs;
+    x.single_agent = single_agent;
+    if (single_agent >= 0) {
+        x.n_emit = 1;
+        x.emit[0] = single_agent;
+    } else {
+        x.n_emit = env->n_emit;
+        for (int i = 0; i < 4; ++i) x.emit[i] = env->emit[i];
+    }
+    HIP_TRY(pmx_launch_expand(&x, env->cfg.obs_dtype, st));
+    return PMX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pmx_version(void) { return PMX_VERSION; }
+const char *pmx_last_error(void) { return g_err; }
+
+int pmx_create(const pmx_config *cfg, pmx_env **out)
+{
+    if (!cfg || !out) return fail(PMX_ERR_INVALID, "pmx_create: null argument");
+    *out = nullptr;
+    const int W = cfg->width, H = cfg->height;
+    if (W < 8 || W > PMX_MAX_DIM || H < 3 || H > PMX_MAX_DIM)
+        return fail(PMX_ERR_UNSUPPORTED, "layout %dx%d outside the supported 8..32 x 3..32", W, H);
+    if (!cfg->wall_rows || !cfg->food_rows || !cfg->cap_rows || !cfg->starts)
+        return fail(PMX_ERR_INVALID, "pmx_create: layout arrays missing");
+    if (cfg->n_envs < 1) return fail(PMX_ERR_INVALID, "n_envs must be >= 1");
+    if (cfg->obs_dtype < PMX_OBS_F32 || cfg->obs_dtype > PMX_OBS_U8) return fail(PMX_ERR_INVALID, "bad obs_dtype");
+    if (cfg->obs_dtype == PMX_OBS_U8 && ((H * W) & 1))
+        return fail(PMX_ERR_UNSUPPORTED, "uint8 observations need an even number of cells (16-byte rows of the stream)");
+    const uint32_t full = W == 32 ? 0xFFFFFFFFu : ((1u << W) - 1u);
+    PmxLayoutDev L;
+    std::memset(&L, 0, sizeof(L));
+    L.W = W; L.H = H; L.half = W / 2;
+    L.lo_mask = (1u << L.half) - 1u;
+    L.hi_mask = full & ~L.lo_mask;
+    int n_caps = 0;
+    uint16_t capslots[4] = { 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF };
+    for (int y = 0; y < H; ++y) {
+        const uint32_t w = cfg->wall_rows[y], f = cfg->food_rows[y], c = cfg->cap_rows[y];
+        if ((w | f | c) & ~full) return fail(PMX_ERR_INVALID, "row %d has bits beyond the width", y);
+        if ((w & f) || (w & c) || (f & c)) return fail(PMX_ERR_INVALID, "row %d: wall/food/capsule overlap", y);
+        const bool border = (y == 0 || y == H - 1);
+        if (border ? (w != full) : (!(w & 1u) || !((w >> (W - 1)) & 1u)))
+            return fail(PMX_ERR_INVALID, "row %d: the layout must be enclosed by walls (game.py:335-350 indexes neighbours)", y);
+        L.walls[y] = w;
+        L.food0[y] = f;
+        L.total_food += __builtin_popcount(f);
+        for (int x = 0; x < W; ++x)
+            if ((c >> x) & 1u) {
+                if (n_caps == PMX_MAX_CAPSULES) return fail(PMX_ERR_UNSUPPORTED, "more than %d capsules", PMX_MAX_CAPSULES);
+                capslots[n_caps++] = (uint16_t)(x | (y << 8));
+            }
+    }
+    L.capw0[0] = capslots[0] | ((uint32_t)capslots[1] << 16);
+    L.capw0[1] = capslots[2] | ((uint32_t)capslots[3] << 16);
+    for (int i = 0; i < 4; ++i) {
+        const int sx = cfg->starts[2 * i], sy = cfg->starts[2 * i + 1];
+        if (sx <= 0 || sy <= 0 || sx >= W - 1 || sy >= H - 1 || ((L.walls[sy] >> sx) & 1u))
+            return fail(PMX_ERR_INVALID, "agent %d start (%d,%d) is not an open interior cell", i, sx, sy);
+        const bool red = 2 * sx < W;   // capture.py:325-330
+        if (red != ((i & 1) == 0))
+            return fail(PMX_ERR_UNSUPPORTED, "agent %d starts on the %s half: gymPacMan.py:150,185,210 hard-codes red = agents 0,2",
+                        i, red ? "red" : "blue");
+        L.startx[i] = sx; L.starty[i] = sy;
+    }
+    L.div_mul = ((1u << 20) + W - 1) / W;
+    for (uint32_t e = 0; e < (uint32_t)(8 * H * W); ++e)
+        if (((e * L.div_mul) >> 20) != e / W) return fail(PMX_ERR_UNSUPPORTED, "internal: reciprocal for width %d inexact", W);
+    const std::vector<int8_t> dump = dump_order(std::max(W, H));
+    L.n_dump = (int)(dump.size() / 2);
+
+    pmx_env *env = new (std::nothrow) pmx_env();
+    if (!env) return fail(PMX_ERR_NOMEM, "host allocation failed");
+    env->cfg = *cfg;
+    env->cfg.wall_rows = env->cfg.food_rows = env->cfg.cap_rows = nullptr;
+    env->cfg.starts = nullptr;
+    env->lay = L;
+    env->open_agent = 0;
+    const int mask = (cfg->obs_agents & 0xF) ? (cfg->obs_agents & 0xF) : 0xF;
+    env->cfg.obs_agents = mask;
+    env->n_emit = 0;
+    for (int i = 0; i < 4; ++i)
+        if ((mask >> i) & 1) env->emit[env->n_emit++] = i;
+    env->elem_bytes = cfg->obs_dtype == PMX_OBS_F32 ? 4 : (cfg->obs_dtype == PMX_OBS_BF16 ? 2 : 1);
+    env->cell_index.assign(32 * 32, -1);
+    for (int x = 0; x < W; ++x)           // Grid.asList(False): x outer, y inner (game.py:225-230)
+        for (int y = 0; y < H; ++y)
+            if (!((L.walls[y] >> x) & 1u)) {
+                env->cell_index[y * 32 + x] = (int16_t)(env->cells.size() / 2);
+                env->cells.push_back((int8_t)x);
+                env->cells.push_back((int8_t)y);
+            }
+    env->lay_dev = nullptr; env->dump_dev = nullptr; env->state_dev = nullptr; env->snap_dev = nullptr;
+
+    hipError_t e = hipSetDevice(cfg->device);
+    const size_t N = (size_t)cfg->n_envs;
+    if (e == hipSuccess) e = hipMalloc((void **)&env->lay_dev, sizeof(PmxLayoutDev));
+    if (e == hipSuccess) e = hipMalloc((void **)&env->dump_dev, dump.size());
+    if (e == hipSuccess) e = hipMalloc((void **)&env->state_dev, PMX_STATE_WORDS(H) * N * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&env->snap_dev, 3 * (size_t)PMX_SNAP_WORDS(H) * N * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(env->lay_dev, &L, sizeof(L), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(env->dump_dev, dump.data(), dump.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        pmx_destroy(env);
+        return fail(e == hipErrorOutOfMemory ? PMX_ERR_NOMEM : PMX_ERR_HIP, "pmx_create: %s", hipGetErrorString(e));
+    }
+    int rc = pmx_reset(env, nullptr, nullptr, nullptr);
+    if (rc == PMX_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(PMX_ERR_HIP, "pmx_create: initial reset failed");
+    if (rc != PMX_OK) { pmx_destroy(env); return rc; }
+    *out = env;
+    return PMX_OK;
+}
+
+int pmx_destroy(pmx_env *env)
+{
+    if (!env) return PMX_OK;
+    if (env->lay_dev) (void)hipFree(env->lay_dev);
+    if (env->dump_dev) (void)hipFree(env->dump_dev);
+    if (env->state_dev) (void)hipFree(env->state_dev);
+    if (env->snap_dev) (void)hipFree(env->snap_dev);
+    delete env;
+    return PMX_OK;
+}
+
+int pmx_obs_shape(const pmx_env *env, int32_t *n_emit, int32_t *height, int32_t *width, int32_t *elem_bytes)
+{
+    if (!env) return fail(PMX_ERR_INVALID, "null env");
+    if (n_emit) *n_emit = env->n_emit;
+    if (height) *height = env->lay.H;
+    if (width) *width = env->lay.W;
+    if (elem_bytes) *elem_bytes = env->elem_bytes;
+    return PMX_OK;
+}
+
+int pmx_reset(pmx_env *env, const uint8_t *mask_dev, const pmx_step_out *out, void *stream)
+{
+    if (!env) return fail(PMX_ERR_INVALID, "null env");
+    PmxTickParams p;
+    fill_tick_params(env, p, nullptr, nullptr);
+    p.reset_mask = mask_dev;
+    p.legal = out ? out->legal_dev : nullptr;
+    HIP_TRY(pmx_launch_reset(&p, env->lay.H, as_stream(stream)));
+    env->open_agent = 0;
+    if (out && out->obs_dev) return launch_expand(env, out->obs_dev, false, -1, as_stream(stream));
+    return PMX_OK;
+}
+
+int pmx_step(pmx_env *env, const int8_t *actions_dev, const pmx_step_out *out, void *stream)
+{
+    if (!env || !actions_dev) return fail(PMX_ERR_INVALID, "pmx_step: null argument");
+    if (env->open_agent != 0) return fail(PMX_ERR_INVALID, "pmx_step: a tick opened with pmx_step_agent is unfinished");
+    PmxTickParams p;
+    fill_tick_params(env, p, actions_dev, out);
+    HIP_TRY(pmx_launch_rule(&p, env->lay.H, as_stream(stream)));
+    if (out && out->obs_dev) return launch_expand(env, out->obs_dev, true, -1, as_stream(stream));
+    return PMX_OK;
+}
+
+int pmx_step_agent(pmx_env *env, int agent, const int8_t *actions_dev, const pmx_step_out *out, void *stream)
+{
+    if (!env || !actions_dev) return fail(PMX_ERR_INVALID, "pmx_step_agent: null argument");
+    if (agent != env->open_agent)
+        return fail(PMX_ERR_INVALID, "pmx_step_agent: expected agent %d, got %d (sub-steps run 0,1,2,3)", env->open_agent, agent);
+    PmxTickParams p;
+    fill_tick_params(env, p, actions_dev, agent == 3 ? out : nullptr);
+    HIP_TRY(pmx_launch_rule_agent(&p, env->lay.H, agent, as_stream(stream)));
+    env->open_agent = (agent + 1) & 3;
+    if (out && out->obs_dev) return launch_expand(env, out->obs_dev, false, agent, as_stream(stream));
+    return PMX_OK;
+}
+
+int pmx_observe(pmx_env *env, void *obs_dev, uint8_t *legal_dev, void *stream)
+{
+    if (!env) return fail(PMX_ERR_INVALID, "null env");
+    if (legal_dev) {
+        PmxTickParams p;
+        fill_tick_params(env, p, nullptr, nullptr);
+        p.legal = legal_dev;
+        p.no_reset = 1;
+        HIP_TRY(pmx_launch_reset(&p, env->lay.H, as_stream(stream)));
+    }
+    if (obs_dev) return launch_expand(env, obs_dev, false, -1, as_stream(stream));
+    return PMX_OK;
+}
+
+// ---- host <-> device state exchange --------------------------------------------------------------------------
+
+int pmx_get_state(pmx_env *env, int32_t first, int32_t count, pmx_state *states, void *stream)
+{
+    if (!env || !states) return fail(PMX_ERR_INVALID, "pmx_get_state: null argument");
+    const int N = env->cfg.n_envs, H = env->lay.H;
+    if (first < 0 || count < 0 || first + count > N) return fail(PMX_ERR_INVALID, "pmx_get_state: range outside [0,%d)", N);
+    if (count == 0) return PMX_OK;
+    const int words = PMX_STATE_WORDS(H);
+    std::vector<uint32_t> buf((size_t)words * count);
+    HIP_TRY(hipMemcpy2DAsync(buf.data(), (size_t)count * 4, env->state_dev + first, (size_t)N * 4, (size_t)count * 4, words,
+                             hipMemcpyDeviceToHost, as_stream(stream)));
+    HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    for (int k = 0; k < count; ++k) {
+        pmx_state &s = states[k];
+        std::memset(&s, 0, sizeof(s));
+        auto word = [&](int w) { return buf[(size_t)w * count + k]; };
+        for (int y = 0; y < H; ++y) s.food[y] = word(y);
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t a = word(PMX_W_AGENT_A(H, i)), b = word(PMX_W_AGENT_B(H, i));
+            s.pos[i][0] = (int8_t)(a & 0xFF); s.pos[i][1] = (int8_t)((a >> 8) & 0xFF);
+            s.dir[i] = (int8_t)((a >> 16) & 0xFF); s.pac[i] = (uint8_t)((a >> 24) & 1);
+            s.scared[i] = (uint8_t)(b & 0xFF); s.carry[i] = (uint16_t)((b >> 8) & 0xFFF); s.ret[i] = (uint16_t)((b >> 20) & 0xFFF);
+        }
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t c = (word(PMX_W_CAPS(H, j >> 1)) >> (16 * (j & 1))) & 0xFFFFu;
+            if (c != 0xFFFFu) s.caps[c >> 8] |= 1u << (c & 0xFF);
+        }
+        s.score = (int32_t)word(PMX_W_SCORE(H));
+        s.steps = (int32_t)word(PMX_W_STEPS(H));
+    }
+    return PMX_OK;
+}
+
+int pmx_set_state(pmx_env *env, int32_t first, int32_t count, const pmx_state *states, void *stream)
+{
+    if (!env || !states) return fail(PMX_ERR_INVALID, "pmx_set_state: null argument");
+    const int N = env->cfg.n_envs, H = env->lay.H, W = env->lay.W;
+    if (first < 0 || count < 0 || first + count > N) return fail(PMX_ERR_INVALID, "pmx_set_state: range outside [0,%d)", N);
+    if (count == 0) return PMX_OK;
+    const int words = PMX_STATE_WORDS(H);
+    std::vector<uint32_t> buf((size_t)words * count, 0);
+    for (int k = 0; k < count; ++k) {
+        const pmx_state &s = states[k];
+        auto word = [&](int w) -> uint32_t & { return buf[(size_t)w * count + k]; };
+        uint16_t slots[4] = { 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF };
+        int nc = 0;
+        for (int y = 0; y < H; ++y) {
+            if ((s.food[y] | s.caps[y]) & env->lay.walls[y]) return fail(PMX_ERR_INVALID, "state %d: food/capsule inside a wall (row %d)", k, y);
+            word(y) = s.food[y];
+            for (int x = 0; x < W; ++x)
+                if ((s.caps[y] >> x) & 1u) {
+                    if (nc == PMX_MAX_CAPSULES) return fail(PMX_ERR_UNSUPPORTED, "state %d: more than %d capsules", k, PMX_MAX_CAPSULES);
+                    slots[nc++] = (uint16_t)(x | (y << 8));
+                }
+        }
+        for (int i = 0; i < 4; ++i) {
+            const int x = s.pos[i][0], y = s.pos[i][1];
+            if (x <= 0 || y <= 0 || x >= W - 1 || y >= H - 1 || ((env->lay.walls[y] >> x) & 1u))
+                return fail(PMX_ERR_INVALID, "state %d: agent %d at (%d,%d) is not on an open interior cell", k, i, x, y);
+            if (s.dir[i] < 0 || s.dir[i] > 4 || s.carry[i] > 0xFFF || s.ret[i] > 0xFFF)
+                return fail(PMX_ERR_INVALID, "state %d: agent %d field out of range", k, i);
+            word(PMX_W_AGENT_A(H, i)) = (uint32_t)x | ((uint32_t)y << 8) | ((uint32_t)s.dir[i] << 16) | ((uint32_t)(s.pac[i] != 0) << 24);
+            word(PMX_W_AGENT_B(H, i)) = (uint32_t)s.scared[i] | ((uint32_t)s.carry[i] << 8) | ((uint32_t)s.ret[i] << 20);
+        }
+        word(PMX_W_CAPS(H, 0)) = slots[0] | ((uint32_t)slots[1] << 16);
+        word(PMX_W_CAPS(H, 1)) = slots[2] | ((uint32_t)slots[3] << 16);
+        word(PMX_W_SCORE(H)) = (uint32_t)s.score;
+        word(PMX_W_STEPS(H)) = (uint32_t)s.steps;
+    }
+    HIP_TRY(hipMemcpy2DAsync(env->state_dev + first, (size_t)N * 4, buf.data(), (size_t)count * 4, (size_t)count * 4, words,
+                             hipMemcpyHostToDevice, as_stream(stream)));
+    HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    env->open_agent = 0;
+    return PMX_OK;
+}
+
+int pmx_maze_distances(pmx_env *env, int8_t *cells_dev, uint8_t *dist_dev, int32_t *n_cells, void *stream)
+{
+    if (!env) return fail(PMX_ERR_INVALID, "null env");
+    const int n = (int)(env->cells.size() / 2);
+    if (n_cells) *n_cells = n;
+    if (cells_dev) HIP_TRY(hipMemcpyAsync(cells_dev, env->cells.data(), env->cells.size(), hipMemcpyHostToDevice, as_stream(stream)));
+    if (!dist_dev) return PMX_OK;
+    if (!cells_dev) return fail(PMX_ERR_INVALID, "pmx_maze_distances: cells_dev is required with dist_dev");
+    int16_t *idx_dev = nullptr;
+    HIP_TRY(hipMallocAsync((void **)&idx_dev, env->cell_index.size() * sizeof(int16_t), as_stream(stream)));
+    HIP_TRY(hipMemcpyAsync(idx_dev, env->cell_index.data(), env->cell_index.size() * sizeof(int16_t), hipMemcpyHostToDevice,
+                           as_stream(stream)));
+    hipError_t e = pmx_launch_maze(env->lay_dev, idx_dev, n, cells_dev, dist_dev, as_stream(stream));
+    // the host vectors outlive the async copies only if we wait for them here
+    HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    HIP_TRY(hipFreeAsync(idx_dev, as_stream(stream)));
+    if (e != hipSuccess) return fail(PMX_ERR_HIP, "pmx_maze_distances: %s", hipGetErrorString(e));
+    return PMX_OK;
+}
+
+}  // extern "C"

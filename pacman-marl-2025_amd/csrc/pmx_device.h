@@ -1,0 +1,67 @@
+// pmx_device.h -- structures shared by the HIP kernels and the C-ABI host code (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PMX_BLOCK 256            // 4 wavefronts of 64
+#define PMX_SCARED_TIME 40       // capture.py:75
+#define PMX_MIN_FOOD 2           // capture.py:70
+
+// ---------------------------------------------------------------------------------------------
+// Device state layout: structure-of-arrays of 32-bit words, word-major: state[word * N + env].
+// One lane owns one env in the rule kernel, so every access below is a fully coalesced dword stream.
+//   [0, H)        food rows, bit x of row y
+//   H + i         agent i word A: x | y << 8 | dir << 16 | isPacman << 24
+//   H + 4 + i     agent i word B: scaredTimer | numCarrying << 8 (12 bits) | numReturned << 20 (12 bits)
+//   H + 8, H + 9  capsule list: four 16-bit slots (x | y << 8), 0xFFFF = empty
+//   H + 10        score (int32)
+//   H + 11        steps (int32)
+//   H + 12 ...    accumulators of an open tick, used only by pmx_step_agent:
+//                 red reward (2 words, f64), blue reward (2 words), red score change, blue score change, total
+// A "snapshot" is the first H + 10 words of this layout; the observation encoder reads snapshots.
+// ---------------------------------------------------------------------------------------------
+#define PMX_W_AGENT_A(H, i) ((H) + (i))
+#define PMX_W_AGENT_B(H, i) ((H) + 4 + (i))
+#define PMX_W_CAPS(H, j) ((H) + 8 + (j))
+#define PMX_W_SCORE(H) ((H) + 10)
+#define PMX_W_STEPS(H) ((H) + 11)
+#define PMX_W_ACC(H) ((H) + 12)
+#define PMX_SNAP_WORDS(H) ((H) + 10)
+#define PMX_STATE_WORDS(H) ((H) + 19)
+
+struct PmxLayoutDev {
+    int32_t W, H, half;          // half = int(W / 2): the food split (capture.py:333)
+    uint32_t lo_mask, hi_mask;   // columns x < half / x >= half
+    uint32_t walls[32];
+    uint32_t food0[32];
+    uint32_t capw0[2];
+    int32_t startx[4], starty[4];
+    int32_t total_food;
+    int32_t n_dump;              // entries of the dump-order table
+    uint32_t div_mul;            // e / W == (e * div_mul) >> 20 for every element index e < 8*H*W
+};
+
+struct PmxTickParams {
+    uint32_t *state;             // [PMX_STATE_WORDS][N]
+    uint32_t *snap;              // [3][PMX_SNAP_WORDS][N] states after sub-steps 0,1,2
+    const PmxLayoutDev *lay;
+    const int8_t *dump;          // [n_dump][2] BFS visit order of dumpFoodFromDeath
+    const int8_t *actions;
+    int32_t N, length, legal_reward, defence_reward, auto_reset;
+    double *reward;
+    uint8_t *done;
+    uint8_t *legal;
+    int32_t *score_change;
+    int32_t *score;
+    const uint8_t *reset_mask;   // reset kernel only: NULL = every env
+    int32_t no_reset;            // reset kernel only: 1 = touch no env (legal masks of the current state only)
+};
+
+struct PmxExpandParams {
+    const uint32_t *snap[4];     // per AGENT: base of the snapshot its planes are encoded from
+    const PmxLayoutDev *lay;
+    void *obs;                   // [N][n_emit][8][H][W]
+    int32_t N, n_emit;
+    int32_t emit[4];             // agent index of each emitted slot
+    int32_t single_agent;        // >= 0: obs is [N][8][H][W] for that agent only (pmx_step_agent)
+};

@@ -1,0 +1,556 @@
+// pmx_step.hip -- the batched Capture-the-Flag tick for gfx950 (MI355X).
+//
+// Two kernels per tick:
+//   pmx_rule_kernel    one LANE per env: the four agent sub-steps of gymPacMan.step (gymPacMan.py:143-193) with the
+//                      rules of capture.py:448-728, the shaped reward of gymPacMan.py:231-259 and the termination
+//                      test of gymPacMan.py:261-270.  Food rows live in LDS (one column per lane, conflict free),
+//                      agents in registers.  It leaves the state after each sub-step as a coalesced SoA snapshot.
+//   pmx_expand_kernel  one WAVEFRONT per (env, agent): turns a snapshot into the 8 observation planes of
+//                      gymPacMan.get_Observation (gymPacMan.py:195-229) with 16-byte-per-lane streaming stores.
+//                      This kernel moves >95 % of the bytes of the tick and is the HBM-roofline kernel.
+// The split keeps the divergent integer rule logic at 64 envs per wave while the byte-heavy expansion gets
+// N*4 wavefronts of perfectly coalesced stores regardless of N.
+#include "pmx_device.h"
+
+namespace {
+
+struct Env {
+    int x[4], y[4], dir[4], pac[4], scared[4], carry[4], ret[4];
+    uint32_t capw[2];
+    int score, steps;
+};
+
+struct Acc {
+    double red_r, blue_r;
+    int red_sc, blue_sc, sc_total;
+};
+
+struct Ctx {
+    const uint32_t *wl;   // LDS: wall rows of the layout
+    uint32_t *fd;         // LDS: this lane's food column, row y at fd[y * PMX_BLOCK]
+    const PmxLayoutDev *L;
+    const int8_t *dump;
+    int W, H, half, n_dump;
+    int legal_reward, defence_reward;
+};
+
+__device__ __forceinline__ uint32_t pack_a(const Env &e, int i)
+{
+    return (uint32_t)e.x[i] | ((uint32_t)e.y[i] << 8) | ((uint32_t)e.dir[i] << 16) | ((uint32_t)e.pac[i] << 24);
+}
+__device__ __forceinline__ uint32_t pack_b(const Env &e, int i)
+{
+    return (uint32_t)e.scared[i] | ((uint32_t)e.carry[i] << 8) | ((uint32_t)e.ret[i] << 20);
+}
+__device__ __forceinline__ void unpack_a(Env &e, int i, uint32_t w)
+{
+    e.x[i] = w & 0xFF; e.y[i] = (w >> 8) & 0xFF; e.dir[i] = (w >> 16) & 0xFF; e.pac[i] = (w >> 24) & 1;
+}
+__device__ __forceinline__ void unpack_b(Env &e, int i, uint32_t w)
+{
+    e.scared[i] = w & 0xFF; e.carry[i] = (w >> 8) & 0xFFF; e.ret[i] = (w >> 20) & 0xFFF;
+}
+
+// capture.py:453-461 + game.py:335-350: bit a = action a legal (0 N, 1 E, 2 S, 3 W, 4 Stop)
+__device__ __forceinline__ int legal_mask(const uint32_t *wl, int x, int y)
+{
+    uint32_t r0 = ~wl[y], rn = ~wl[y + 1], rs = ~wl[y - 1];
+    return (int)(((rn >> x) & 1u) | (((r0 >> (x + 1)) & 1u) << 1) | (((rs >> x) & 1u) << 2) |
+                 (((r0 >> (x - 1)) & 1u) << 3) | (((r0 >> x) & 1u) << 4));
+}
+
+__device__ __forceinline__ int cap_find(const Env &e, int x, int y)
+{
+    uint32_t key = (uint32_t)x | ((uint32_t)y << 8);
+    if ((e.capw[0] & 0xFFFFu) == key) return 0;
+    if ((e.capw[0] >> 16) == key) return 1;
+    if ((e.capw[1] & 0xFFFFu) == key) return 2;
+    if ((e.capw[1] >> 16) == key) return 3;
+    return -1;
+}
+__device__ __forceinline__ void cap_remove(Env &e, int slot)
+{
+    uint32_t m = 0xFFFFu << (16 * (slot & 1));
+    if (slot < 2) e.capw[0] |= m; else e.capw[1] |= m;
+}
+
+__device__ __forceinline__ void send_home(Env &e, const Ctx &c, int i)
+{   // capture.py:691-693 / 699-701 / 717-719 / 725-727
+    e.pac[i] = 0; e.x[i] = c.L->startx[i]; e.y[i] = c.L->starty[i]; e.dir[i] = 4; e.scared[i] = 0;
+}
+
+// capture.py:569-668 dumpFoodFromDeath.  The reference's FIFO BFS visits offsets in a board-independent order;
+// c.dump holds that order (generated on the host by running the same BFS), so the walk is a linear scan.
+__device__ __forceinline__ void dump_food(Env &e, const Ctx &c, int who_x, int who_y, int num, int &d_red, int &d_blue)
+{
+    const int side_red = 2 * who_x < c.W;
+    for (int k = 0; k < c.n_dump && num > 0; ++k) {
+        int X = who_x + c.dump[2 * k], Y = who_y + c.dump[2 * k + 1];
+        if (X <= 0 || Y <= 0 || X >= c.W || Y >= c.H) continue;          // :609
+        if ((c.wl[Y] >> X) & 1u) continue;                                // :612
+        uint32_t row = c.fd[Y * PMX_BLOCK];
+        if ((row >> X) & 1u) continue;                                    // :614
+        if ((2 * X < c.W) != side_red) continue;                          // :618
+        if (cap_find(e, X, Y) >= 0) continue;                             // :621
+        bool occ = false;                                                 // :625-627
+#pragma unroll
+        for (int i = 0; i < 4; ++i) occ |= (e.x[i] == X && e.y[i] == Y);
+        if (occ) continue;
+        c.fd[Y * PMX_BLOCK] = row | (1u << X);
+        --num;
+        if (X < c.half) ++d_red; else ++d_blue;
+    }
+}
+
+template <int WHO>
+__device__ __forceinline__ void kill_dump(Env &e, const Ctx &c, int &d_red, int &d_blue)
+{
+    if (e.pac[WHO] && e.carry[WHO] > 0) dump_food(e, c, e.x[WHO], e.y[WHO], e.carry[WHO], d_red, d_blue);
+    if (e.pac[WHO]) e.carry[WHO] = 0;   // (a non-Pacman here is the reference's "seriously wrong" raise: unreachable)
+}
+
+// capture.py:519-560 consume, for an eater of team RED / blue standing on (px, py)
+template <bool RED>
+__device__ __forceinline__ void consume(Env &e, const Ctx &c, int px, int py, int &d_red, int &d_blue)
+{
+    uint32_t row = c.fd[py * PMX_BLOCK];
+    if ((row >> px) & 1u) {
+        constexpr int T1 = RED ? 0 : 1, T2 = T1 + 2;                      // :533-537 team order
+        if (e.x[T1] == px && e.y[T1] == py) e.carry[T1] += 1;
+        else if (e.x[T2] == px && e.y[T2] == py) e.carry[T2] += 1;
+        c.fd[py * PMX_BLOCK] = row & ~(1u << px);
+        if (px < c.half) --d_red; else --d_blue;
+    }
+    int slot = cap_find(e, px, py);
+    if (slot >= 0) {
+        bool mine = RED ? (2 * px > c.W) : (2 * px <= c.W);               // halfList, capture.py:344-350
+        if (mine) {
+            cap_remove(e, slot);
+            constexpr int O1 = RED ? 1 : 0, O2 = O1 + 2;
+            e.scared[O1] = PMX_SCARED_TIME; e.scared[O2] = PMX_SCARED_TIME;
+        }
+    }
+}
+
+// capture.py:107-123 generateSuccessor for mover I, in place.  Returns scoreChange; d_red/d_blue receive the net
+// change of the food counts on the red / blue side (what gymPacMan.get_reward compares, gymPacMan.py:234-247).
+template <int I>
+__device__ __forceinline__ int substep(Env &e, const Ctx &c, int action, bool &req_legal, int &d_red, int &d_blue)
+{
+    constexpr bool RED = (I % 2) == 0;
+    constexpr int O1 = RED ? 1 : 0, O2 = O1 + 2;
+    // ---- applyAction capture.py:468-517
+    const int legal = legal_mask(c.wl, e.x[I], e.y[I]);
+    req_legal = (action >= 0) && (action <= 4) && ((legal >> (action & 7)) & 1);
+    if (!req_legal) action = 4;                                           // :473-474
+    const int dx = (action == 1) - (action == 3), dy = (action == 0) - (action == 2);
+    e.x[I] += dx; e.y[I] += dy;
+    if (action != 4) e.dir[I] = action;                                   // game.py:115-118
+    const int px = e.x[I], py = e.y[I];
+    e.pac[I] = (int)(RED != (2 * px < c.W));                              // :492
+    int eater_pac = e.pac[I];
+    int sc = 0;
+    if (e.carry[I] > 0 && !e.pac[I]) {                                    // :495-511
+        sc = RED ? e.carry[I] : -e.carry[I];
+        e.ret[I] += e.carry[I];
+        e.carry[I] = 0;
+        eater_pac = e.pac[3];                                             // :505 leaves agentState bound to agent 3
+    }
+    if (eater_pac) consume<RED>(e, c, px, py, d_red, d_blue);            // :514-515
+    // ---- checkDeath capture.py:670-728; the isPacman branch is chosen once, positions are re-read per opponent
+    if (e.pac[I]) {
+        if (!e.pac[O1] && e.x[O1] == e.x[I] && e.y[O1] == e.y[I]) {
+            if (e.scared[O1] <= 0) { kill_dump<I>(e, c, d_red, d_blue); send_home(e, c, I); }
+            else send_home(e, c, O1);
+        }
+        if (!e.pac[O2] && e.x[O2] == e.x[I] && e.y[O2] == e.y[I]) {
+            if (e.scared[O2] <= 0) { kill_dump<I>(e, c, d_red, d_blue); send_home(e, c, I); }
+            else send_home(e, c, O2);
+        }
+    } else {
+        if (e.pac[O1] && e.x[O1] == e.x[I] && e.y[O1] == e.y[I]) {
+            if (e.scared[I] <= 0) { kill_dump<O1>(e, c, d_red, d_blue); send_home(e, c, O1); }
+            else send_home(e, c, I);
+        }
+        if (e.pac[O2] && e.x[O2] == e.x[I] && e.y[O2] == e.y[I]) {
+            if (e.scared[I] <= 0) { kill_dump<O2>(e, c, d_red, d_blue); send_home(e, c, O2); }
+            else send_home(e, c, I);
+        }
+    }
+    e.scared[I] = e.scared[I] > 1 ? e.scared[I] - 1 : 0;                  // capture.py:562-567, mover only
+    e.score += sc;                                                        // capture.py:121
+    return sc;
+}
+
+// One iteration of the loop gymPacMan.py:149-169 for agent I: shaped reward (from the successor, which is what the
+// reference's shadow successor equals) + the transition itself.
+template <int I>
+__device__ __forceinline__ void tick_substep(Env &e, Acc &a, const Ctx &c, int action)
+{
+    constexpr bool RED = (I % 2) == 0;
+    constexpr int O1 = RED ? 1 : 0, O2 = O1 + 2;
+    const int pac1 = e.pac[O1], pac2 = e.pac[O2];
+    bool req_legal;
+    int d_red = 0, d_blue = 0;
+    const int sc = substep<I>(e, c, action, req_legal, d_red, d_blue);
+    double r = RED ? a.red_r : a.blue_r;
+    if (RED) {                                                            // gymPacMan.py:233-242
+        if (d_red > 0) r += 1.0;
+        if (d_blue < 0) r += 0.1;
+    } else {                                                              // :244-253
+        if (d_blue > 0) r += 1.0;
+        if (d_red < 0) r += 0.1;
+    }
+    if (c.defence_reward) {
+        if (pac1 && !e.pac[O1] && e.x[O1] == c.L->startx[O1] && e.y[O1] == c.L->starty[O1]) r += 0.25;
+        if (pac2 && !e.pac[O2] && e.x[O2] == c.L->startx[O2] && e.y[O2] == c.L->starty[O2]) r += 0.25;
+    }
+    if (c.legal_reward && req_legal) r += 0.01;                           // :254-257
+    if (RED) { a.red_r = r; a.red_sc += sc; } else { a.blue_r = r; a.blue_sc -= sc; }
+    a.sc_total += sc;                                                     // :153-162
+}
+
+__device__ __forceinline__ void load_env(Env &e, const Ctx &c, const uint32_t *st, int N, int env)
+{
+    for (int y = 0; y < c.H; ++y) c.fd[y * PMX_BLOCK] = st[(size_t)y * N + env];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unpack_a(e, i, st[(size_t)PMX_W_AGENT_A(c.H, i) * N + env]);
+        unpack_b(e, i, st[(size_t)PMX_W_AGENT_B(c.H, i) * N + env]);
+    }
+    e.capw[0] = st[(size_t)PMX_W_CAPS(c.H, 0) * N + env];
+    e.capw[1] = st[(size_t)PMX_W_CAPS(c.H, 1) * N + env];
+    e.score = (int)st[(size_t)PMX_W_SCORE(c.H) * N + env];
+    e.steps = (int)st[(size_t)PMX_W_STEPS(c.H) * N + env];
+}
+
+// first PMX_SNAP_WORDS words (food, agents, capsules)
+__device__ __forceinline__ void store_snapshot(const Env &e, const Ctx &c, uint32_t *st, int N, int env)
+{
+    for (int y = 0; y < c.H; ++y) st[(size_t)y * N + env] = c.fd[y * PMX_BLOCK];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        st[(size_t)PMX_W_AGENT_A(c.H, i) * N + env] = pack_a(e, i);
+        st[(size_t)PMX_W_AGENT_B(c.H, i) * N + env] = pack_b(e, i);
+    }
+    st[(size_t)PMX_W_CAPS(c.H, 0) * N + env] = e.capw[0];
+    st[(size_t)PMX_W_CAPS(c.H, 1) * N + env] = e.capw[1];
+}
+
+__device__ __forceinline__ void store_env(const Env &e, const Ctx &c, uint32_t *st, int N, int env)
+{
+    store_snapshot(e, c, st, N, env);
+    st[(size_t)PMX_W_SCORE(c.H) * N + env] = (uint32_t)e.score;
+    st[(size_t)PMX_W_STEPS(c.H) * N + env] = (uint32_t)e.steps;
+}
+
+// game.py:490-508 GameStateData.initialize + gymPacMan.py:94 steps = 0
+__device__ __forceinline__ void init_env(Env &e, const Ctx &c)
+{
+    for (int y = 0; y < c.H; ++y) c.fd[y * PMX_BLOCK] = c.L->food0[y];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        e.x[i] = c.L->startx[i]; e.y[i] = c.L->starty[i]; e.dir[i] = 4;
+        e.pac[i] = 0; e.scared[i] = 0; e.carry[i] = 0; e.ret[i] = 0;
+    }
+    e.capw[0] = c.L->capw0[0]; e.capw[1] = c.L->capw0[1];
+    e.score = 0; e.steps = 0;
+}
+
+// gymPacMan.py:171-193: everything after the four sub-steps.
+__device__ __forceinline__ void tick_finish(Env &e, Acc &a, const Ctx &c, const PmxTickParams &p, int env)
+{
+    double blue_r = a.blue_r + (double)(a.blue_sc > 0 ? a.blue_sc : 0);   // :171-172
+    double red_r = a.red_r + (double)(a.red_sc > 0 ? a.red_sc : 0);
+    int n_red = 0, n_blue = 0;                                            // capture.py:332-342 halfGrid sums
+    for (int y = 0; y < c.H; ++y) {
+        uint32_t row = c.fd[y * PMX_BLOCK];
+        n_red += __popc(row & c.L->lo_mask);
+        n_blue += __popc(row & c.L->hi_mask);
+    }
+    bool done = (n_blue == 0 && e.carry[0] == 0 && e.carry[2] == 0) ||    // gymPacMan.py:261-270
+                (n_red == 0 && e.carry[1] == 0 && e.carry[3] == 0) || (e.steps >= p.length);
+    if (done) {                                                           // :177-182
+        const int fs = e.score;
+        if (fs < 0) blue_r += 20.0 + (1.0 / 5) * (double)(-fs);
+        else if (fs > 0) red_r += 20.0 + (1.0 / 5) * (double)fs;
+    }
+    e.steps += 1;                                                         // :189
+    if (p.reward) { p.reward[2 * (size_t)env] = red_r; p.reward[2 * (size_t)env + 1] = blue_r; }
+    if (p.done) p.done[env] = (uint8_t)done;
+    if (p.score_change) p.score_change[env] = a.sc_total;
+    if (p.score) p.score[env] = e.score;
+    if (done && p.auto_reset) {
+        init_env(e, c);
+        // the observations of a finished env are those of the fresh game for all four agents (gymPacMan.py:135-137)
+        const size_t snap_sz = (size_t)PMX_SNAP_WORDS(c.H) * p.N;
+        for (int s = 0; s < 3; ++s) store_snapshot(e, c, p.snap + s * snap_sz, p.N, env);
+    }
+    if (p.legal) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m |= (uint32_t)legal_mask(c.wl, e.x[i], e.y[i]) << (8 * i);
+        reinterpret_cast<uint32_t *>(p.legal)[env] = m;
+    }
+}
+
+__device__ __forceinline__ Ctx make_ctx(const PmxTickParams &p, uint32_t *lds)
+{
+    Ctx c;
+    c.L = p.lay;
+    c.W = p.lay->W; c.H = p.lay->H; c.half = p.lay->half; c.n_dump = p.lay->n_dump;
+    c.dump = p.dump;
+    c.legal_reward = p.legal_reward; c.defence_reward = p.defence_reward;
+    c.wl = lds;
+    c.fd = lds + 32 + threadIdx.x;
+    if (threadIdx.x < 32) lds[threadIdx.x] = threadIdx.x < (unsigned)c.H ? p.lay->walls[threadIdx.x] : 0xFFFFFFFFu;
+    __syncthreads();
+    return c;
+}
+
+}  // namespace
+
+// dynamic LDS: 32 wall rows + H food rows x PMX_BLOCK lanes
+extern "C" __global__ __launch_bounds__(PMX_BLOCK) void pmx_rule_kernel(PmxTickParams p)
+{
+    extern __shared__ uint32_t lds[];
+    Ctx c = make_ctx(p, lds);
+    const int env = blockIdx.x * PMX_BLOCK + threadIdx.x;
+    if (env >= p.N) return;
+    Env e;
+    load_env(e, c, p.state, p.N, env);
+    Acc a = { 0.0, 0.0, 0, 0, 0 };
+    const uint32_t av = reinterpret_cast<const uint32_t *>(p.actions)[env];   // 4 int8 actions
+    const size_t snap_sz = (size_t)PMX_SNAP_WORDS(c.H) * p.N;
+    tick_substep<0>(e, a, c, (int)(int8_t)(av & 0xFF));
+    store_snapshot(e, c, p.snap, p.N, env);
+    tick_substep<1>(e, a, c, (int)(int8_t)((av >> 8) & 0xFF));
+    store_snapshot(e, c, p.snap + snap_sz, p.N, env);
+    tick_substep<2>(e, a, c, (int)(int8_t)((av >> 16) & 0xFF));
+    store_snapshot(e, c, p.snap + 2 * snap_sz, p.N, env);
+    tick_substep<3>(e, a, c, (int)(int8_t)((av >> 24) & 0xFF));
+    tick_finish(e, a, c, p, env);
+    store_env(e, c, p.state, p.N, env);
+}
+
+// pmx_step_agent: one sub-step; the accumulators of the open tick travel through the state words.
+template <int I>
+__device__ __forceinline__ void rule_agent_body(const PmxTickParams &p, uint32_t *lds)
+{
+    Ctx c = make_ctx(p, lds);
+    const int env = blockIdx.x * PMX_BLOCK + threadIdx.x;
+    if (env >= p.N) return;
+    Env e;
+    load_env(e, c, p.state, p.N, env);
+    Acc a = { 0.0, 0.0, 0, 0, 0 };
+    uint32_t *acc = p.state + (size_t)PMX_W_ACC(c.H) * p.N + env;
+    if (I > 0) {
+        a.red_r = __hiloint2double((int)acc[(size_t)1 * p.N], (int)acc[0]);
+        a.blue_r = __hiloint2double((int)acc[(size_t)3 * p.N], (int)acc[(size_t)2 * p.N]);
+        a.red_sc = (int)acc[(size_t)4 * p.N]; a.blue_sc = (int)acc[(size_t)5 * p.N]; a.sc_total = (int)acc[(size_t)6 * p.N];
+    }
+    tick_substep<I>(e, a, c, (int)p.actions[env]);
+    if (I == 3) {
+        tick_finish(e, a, c, p, env);
+    } else {
+        acc[0] = (uint32_t)__double2loint(a.red_r); acc[(size_t)1 * p.N] = (uint32_t)__double2hiint(a.red_r);
+        acc[(size_t)2 * p.N] = (uint32_t)__double2loint(a.blue_r); acc[(size_t)3 * p.N] = (uint32_t)__double2hiint(a.blue_r);
+        acc[(size_t)4 * p.N] = (uint32_t)a.red_sc; acc[(size_t)5 * p.N] = (uint32_t)a.blue_sc; acc[(size_t)6 * p.N] = (uint32_t)a.sc_total;
+    }
+    store_env(e, c, p.state, p.N, env);
+}
+
+extern "C" __global__ __launch_bounds__(PMX_BLOCK) void pmx_rule_agent_kernel(PmxTickParams p, int agent)
+{
+    extern __shared__ uint32_t lds[];
+    switch (agent) {   // wave-uniform
+    case 0: rule_agent_body<0>(p, lds); break;
+    case 1: rule_agent_body<1>(p, lds); break;
+    case 2: rule_agent_body<2>(p, lds); break;
+    default: rule_agent_body<3>(p, lds); break;
+    }
+}
+
+// gymPacMan.reset (gymPacMan.py:92-141) for the masked envs; legal masks for all envs if requested
+extern "C" __global__ __launch_bounds__(PMX_BLOCK) void pmx_reset_kernel(PmxTickParams p)
+{
+    extern __shared__ uint32_t lds[];
+    Ctx c = make_ctx(p, lds);
+    const int env = blockIdx.x * PMX_BLOCK + threadIdx.x;
+    if (env >= p.N) return;
+    Env e;
+    if (!p.no_reset && (!p.reset_mask || p.reset_mask[env])) {
+        init_env(e, c);
+        store_env(e, c, p.state, p.N, env);
+        for (int k = 0; k < 7; ++k) p.state[(size_t)(PMX_W_ACC(c.H) + k) * p.N + env] = 0;
+    } else if (p.legal) {
+        load_env(e, c, p.state, p.N, env);
+    }
+    if (p.legal) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m |= (uint32_t)legal_mask(c.wl, e.x[i], e.y[i]) << (8 * i);
+        reinterpret_cast<uint32_t *>(p.legal)[env] = m;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Observation expansion (gymPacMan.py:195-229).  One wavefront per (env, emitted agent).
+//   1. the wave builds a row table T[8*H] in LDS: one 32-bit mask per (plane, y) row of the output;
+//      planes 0, 6, 7 are whole rows (walls, food & blue half, food & red half), planes 1..5 are points
+//      (self, capsules, ally, enemies) OR-ed in by 8 lanes;
+//   2. every lane then produces 16 contiguous output bytes per iteration from a 64-bit window of the row-major
+//      bit stream and stores them with one dwordx4 store: the wave writes 1 KiB of consecutive addresses per
+//      instruction.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DT> struct ObsVec;
+template <> struct ObsVec<0> { static constexpr int VEC = 4; };    // float32
+template <> struct ObsVec<1> { static constexpr int VEC = 8; };    // bfloat16
+template <> struct ObsVec<2> { static constexpr int VEC = 16; };   // uint8
+
+template <int DT>
+__device__ __forceinline__ uint4 pack_obs(uint64_t s, int dself, uint32_t carry)
+{
+    uint4 o;
+    if (DT == 0) {
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            w[j] = ((uint32_t)(s >> j) & 1u) * 0x3F800000u;
+            if (dself == j) w[j] = __float_as_uint((float)(1 + carry));
+        }
+        o = make_uint4(w[0], w[1], w[2], w[3]);
+    } else if (DT == 1) {
+        uint32_t w[4];
+        const uint32_t selfbits = __float_as_uint((float)(1 + carry)) >> 16;   // exact for 1+carry <= 256
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t lo = ((uint32_t)(s >> (2 * k)) & 1u) * 0x3F80u;
+            uint32_t hi = ((uint32_t)(s >> (2 * k + 1)) & 1u) * 0x3F80u;
+            if (dself == 2 * k) lo = selfbits;
+            if (dself == 2 * k + 1) hi = selfbits;
+            w[k] = lo | (hi << 16);
+        }
+        o = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t nib = (uint32_t)(s >> (4 * k)) & 0xFu;
+            w[k] = (nib * 0x00204081u) & 0x01010101u;               // bit j -> byte j
+            if ((dself >> 2) == k && dself >= 0) w[k] += carry << (8 * (dself & 3));
+        }
+        o = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    return o;
+}
+
+template <int DT>
+__global__ __launch_bounds__(PMX_BLOCK) void pmx_expand_kernel(PmxExpandParams p)
+{
+    constexpr int VEC = ObsVec<DT>::VEC;
+    __shared__ uint32_t tab[4][8 * 32 + 8];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const PmxLayoutDev *L = p.lay;
+    const int W = L->W, H = L->H;
+    const long total = (long)p.N * p.n_emit;
+    long blk = blockIdx.x;
+    if (p.n_emit == 4 && (p.N & 127) == 0) {
+        // XCD-aware order: blocks b, b+8, b+16.. share an XCD (and its L2); give each XCD 16 consecutive envs so that
+        // the SoA snapshot words it reads come from the same 64-byte lines.
+        long g = blk >> 7, r = blk & 127;
+        blk = (g << 7) + ((r & 7) << 4) + (r >> 3);
+    }
+    const long q = blk * 4 + wave;
+    const bool active = q < total;
+    const long env = active ? q / p.n_emit : 0;
+    const int slot = active ? (int)(q - env * p.n_emit) : 0;
+    const int agent = p.single_agent >= 0 ? p.single_agent : p.emit[slot];
+    const uint32_t *S = p.snap[agent] + env;
+    const size_t N = (size_t)p.N;
+    uint32_t *T = tab[wave];
+
+    for (int r = H + lane; r < 6 * H; r += 64) T[r] = 0;
+    if (lane < 4) T[8 * H + lane] = 0;
+    if (active && lane < H) {
+        uint32_t f = S[(size_t)lane * N];
+        T[lane] = L->walls[lane];
+        T[6 * H + lane] = f & L->hi_mask;       // blue food: x >= int(W/2) (capture.py:336)
+        T[7 * H + lane] = f & L->lo_mask;       // red food
+    }
+    __syncthreads();
+    if (active && lane < 4) {
+        uint32_t a = S[(size_t)PMX_W_AGENT_A(H, lane) * N];
+        int x = a & 0xFF, y = (a >> 8) & 0xFF;
+        int plane = lane == agent ? 1 : (((lane ^ agent) == 2) ? 4 : 5);   // gymPacMan.py:205-215
+        atomicOr(&T[plane * H + y], 1u << x);
+    } else if (active && lane < 8) {
+        int j = lane - 4;
+        uint32_t w = S[(size_t)PMX_W_CAPS(H, j >> 1) * N];
+        uint32_t cxy = (w >> (16 * (j & 1))) & 0xFFFFu;
+        if (cxy != 0xFFFFu) {
+            int x = cxy & 0xFF, y = cxy >> 8;
+            int plane = (2 * x > W) ? 2 : 3;                                // halfList: blue x > W/2, red x <= W/2
+            atomicOr(&T[plane * H + y], 1u << x);
+        }
+    }
+    const uint32_t a_self = active ? S[(size_t)PMX_W_AGENT_A(H, agent) * N] : 0;
+    const uint32_t b_self = active ? S[(size_t)PMX_W_AGENT_B(H, agent) * N] : 0;
+    const uint32_t carry = (b_self >> 8) & 0xFFF;
+    const int fself = (H + (int)((a_self >> 8) & 0xFF)) * W + (int)(a_self & 0xFF);
+    __syncthreads();
+    if (!active) return;
+
+    const int n_vec = 8 * H * W / VEC;
+    const uint32_t mul = L->div_mul;
+    uint4 *out = reinterpret_cast<uint4 *>(p.obs) + (size_t)q * n_vec;
+    for (int k = lane; k < n_vec; k += 64) {
+        const uint32_t e0 = (uint32_t)k * VEC;
+        const uint32_t r0 = (e0 * mul) >> 20;
+        const int x0 = (int)(e0 - r0 * W);
+        const uint32_t m0 = T[r0], m1 = T[r0 + 1], m2 = T[r0 + 2];
+        int sh2 = 2 * W - x0; sh2 = sh2 > 63 ? 63 : sh2;
+        const uint64_t s = (uint64_t)(m0 >> x0) | ((uint64_t)m1 << (W - x0)) | ((uint64_t)m2 << sh2);
+        out[k] = pack_obs<DT>(s, fself - (int)e0, carry);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host-side launchers (called by the C ABI in pmx_api.hip)
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" hipError_t pmx_launch_rule(const PmxTickParams *p, int H, hipStream_t st)
+{
+    const int blocks = (p->N + PMX_BLOCK - 1) / PMX_BLOCK;
+    const size_t lds = (32 + (size_t)H * PMX_BLOCK) * sizeof(uint32_t);
+    hipLaunchKernelGGL(pmx_rule_kernel, dim3(blocks), dim3(PMX_BLOCK), lds, st, *p);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t pmx_launch_rule_agent(const PmxTickParams *p, int H, int agent, hipStream_t st)
+{
+    const int blocks = (p->N + PMX_BLOCK - 1) / PMX_BLOCK;
+    const size_t lds = (32 + (size_t)H * PMX_BLOCK) * sizeof(uint32_t);
+    hipLaunchKernelGGL(pmx_rule_agent_kernel, dim3(blocks), dim3(PMX_BLOCK), lds, st, *p, agent);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t pmx_launch_reset(const PmxTickParams *p, int H, hipStream_t st)
+{
+    const int blocks = (p->N + PMX_BLOCK - 1) / PMX_BLOCK;
+    const size_t lds = (32 + (size_t)H * PMX_BLOCK) * sizeof(uint32_t);
+    hipLaunchKernelGGL(pmx_reset_kernel, dim3(blocks), dim3(PMX_BLOCK), lds, st, *p);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, int dtype, hipStream_t st)
+{
+    const long waves = (long)p->N * p->n_emit;
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    switch (dtype) {
+    case 0: hipLaunchKernelGGL(pmx_expand_kernel<0>, dim3(blocks), dim3(PMX_BLOCK), 0, st, *p); break;
+    case 1: hipLaunchKernelGGL(pmx_expand_kernel<1>, dim3(blocks), dim3(PMX_BLOCK), 0, st, *p); break;
+    default: hipLaunchKernelGGL(pmx_expand_kernel<2>, dim3(blocks), dim3(PMX_BLOCK), 0, st, *p); break;
+    }
+    return hipGetLastError();
+}

@@ -1,0 +1,228 @@
+// pmx_train.hip -- the non-tick kernels of the path (gfx950): GAE reverse scan, maze distances, observation
+// post-processing.  C-ABI entry points for pmx_gae / pmx_canonicalize_obs / pmx_merge_obs live here too.
+#include <cstdio>
+
+#include "../../include/pmx.h"
+#include "pmx_device.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// GAE (pacman_mappo_resnet.py:277-290), series laid out [T][n].
+//   lane-per-series: the vectorised trainer has n = envs x learners >= thousands of independent series and a short
+//     horizon, so one lane owns one series and walks it backwards; every load/store is a coalesced row of the
+//     [T][n] arrays and the arithmetic is the reference's float32 sequence exactly (bit-exact; contraction is off).
+//   wave-per-series: the reference's own regime (n = 2, T = 2048): A_t = delta_t + c_t * A_{t+1} is a composition of
+//     affine maps, so a wavefront scans 64 time steps at once with a Kogge-Stone prefix over __shfl_up.  The
+//     re-association changes float rounding (documented tolerance 1e-5 relative), so it is used only when there are
+//     too few series to fill the chip.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pmx_gae_lane_kernel(const float *__restrict__ rew, const float *__restrict__ val,
+                                                           const float *__restrict__ done, const float *__restrict__ last,
+                                                           int T, int n, double gamma, double lam, float *__restrict__ adv,
+                                                           float *__restrict__ ret)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float g32 = (float)gamma;
+    const float gl32 = (float)(gamma * lam);              // Python double product, rounded when it meets the tensor
+    float lastgaelam = 0.0f;
+    // gamma * last_value is a double product in the reference (both are Python floats), then rounded to float32
+    float gv = (float)(gamma * (double)last[i]);
+#pragma unroll 4
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t o = (size_t)t * n + i;
+        const float v = val[o];
+        const float nonterm = 1.0f - done[o];
+        const float delta = rew[o] + gv * nonterm - v;
+        lastgaelam = delta + gl32 * nonterm * lastgaelam;
+        adv[o] = lastgaelam;
+        ret[o] = lastgaelam + v;
+        gv = g32 * v;                                      // gamma * values[t] for step t-1
+    }
+}
+
+__global__ __launch_bounds__(64) void pmx_gae_wave_kernel(const float *__restrict__ rew, const float *__restrict__ val,
+                                                          const float *__restrict__ done, const float *__restrict__ last,
+                                                          int T, int n, double gamma, double lam, float *__restrict__ adv,
+                                                          float *__restrict__ ret)
+{
+    const int i = blockIdx.x;                              // one wavefront per series
+    const int lane = threadIdx.x;
+    const float g32 = (float)gamma, gl32 = (float)(gamma * lam);
+    float carry = 0.0f;                                    // A_{t+1} entering the chunk
+    for (int hi = T - 1; hi >= 0; hi -= 64) {
+        const int t = hi - lane;                           // lane 0 = latest time of the chunk
+        float a = 0.0f, b = 0.0f, v = 0.0f;
+        if (t >= 0) {
+            const size_t o = (size_t)t * n + i;
+            v = val[o];
+            const float nonterm = 1.0f - done[o];
+            const float gv = (t == T - 1) ? (float)(gamma * (double)last[i]) : g32 * val[o + n];
+            b = rew[o] + gv * nonterm - v;                 // delta_t
+            a = gl32 * nonterm;
+        }
+        // inclusive scan of x -> a*x + b towards higher lanes (earlier times): f_l o f_{l-1} o ... o f_0
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const float ao = __shfl_up(a, d), bo = __shfl_up(b, d);
+            if (lane >= d) { b = a * bo + b; a = a * ao; }
+        }
+        const float A = a * carry + b;
+        if (t >= 0) {
+            const size_t o = (size_t)t * n + i;
+            adv[o] = A;
+            ret[o] = A + v;
+        }
+        const int last_lane = hi >= 63 ? 63 : hi;
+        carry = __shfl(A, last_lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Maze distances (distanceCalculator.py:111-150): unit-cost UCS from every open cell == BFS.  One lane per SOURCE
+// cell; the frontier / visited sets are 32 row masks held in registers (loops fully unrolled so every index is a
+// compile-time constant), one BFS level is four shifted ORs per row.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void pmx_maze_kernel(const PmxLayoutDev *__restrict__ L, const int16_t *__restrict__ cell_index,
+                                                      int n, const int8_t *__restrict__ cells, uint8_t *__restrict__ dist)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int H = L->H;
+    uint32_t open[32], vis[32], fr[32];
+#pragma unroll
+    for (int y = 0; y < 32; ++y) { open[y] = y < H ? ~L->walls[y] & (L->lo_mask | L->hi_mask) : 0u; vis[y] = 0u; fr[y] = 0u; }
+    const int sx = cells[2 * s], sy = cells[2 * s + 1];
+    for (int t = 0; t < n; ++t) dist[(size_t)t * n + s] = 255;      // sys.maxsize in the reference
+#pragma unroll
+    for (int y = 0; y < 32; ++y) if (y == sy) { fr[y] = 1u << sx; vis[y] = fr[y]; }
+    dist[(size_t)s * n + s] = 0;
+    for (int level = 1; level < 255; ++level) {
+        uint32_t nx[32];
+        uint32_t any = 0;
+#pragma unroll
+        for (int y = 0; y < 32; ++y) {
+            uint32_t m = (fr[y] << 1) | (fr[y] >> 1);
+            if (y > 0) m |= fr[y - 1];
+            if (y < 31) m |= fr[y + 1];
+            m &= open[y] & ~vis[y];
+            nx[y] = m;
+            any |= m;
+        }
+        if (!any) break;
+#pragma unroll
+        for (int y = 0; y < 32; ++y) {
+            fr[y] = nx[y];
+            vis[y] |= nx[y];
+            uint32_t m = nx[y];
+            while (m) {
+                const int x = __ffs(m) - 1;
+                m &= m - 1;
+                const int t = cell_index[y * 32 + x];
+                dist[(size_t)t * n + s] = (uint8_t)level;
+            }
+        }
+    }
+}
+
+extern "C" hipError_t pmx_launch_maze(const PmxLayoutDev *lay_dev, const int16_t *cell_index_dev, int n_cells,
+                                      const int8_t *cells_dev, uint8_t *dist_dev, hipStream_t st)
+{
+    hipLaunchKernelGGL(pmx_maze_kernel, dim3((n_cells + 63) / 64), dim3(64), 0, st, lay_dev, cell_index_dev, n_cells, cells_dev,
+                       dist_dev);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Observation post-processing (pacman_mappo_resnet.py:215-229, :267-274) on [n][8][H][W] blocks.  Observation values
+// are non-negative (0, 1, 1 + carry), so for all three element types the unsigned bit pattern orders like the value.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename E>
+__global__ __launch_bounds__(256) void pmx_canon_kernel(const E *__restrict__ in, E *__restrict__ out, long total, int H, int W)
+{
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total) return;
+    const int x = (int)(k % W);
+    const long r = k / W;
+    const int y = (int)(r % H);
+    const long pc = r / H;
+    const int c = (int)(pc & 7);
+    const long b = pc >> 3;
+    const int sc = (c == 2) ? 3 : (c == 3) ? 2 : (c == 6) ? 7 : (c == 7) ? 6 : c;
+    out[k] = in[((b * 8 + sc) * H + y) * W + (W - 1 - x)];
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void pmx_merge_kernel(const E *__restrict__ a, const E *__restrict__ b, E *__restrict__ out,
+                                                        long total, int plane)
+{
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total) return;
+    const int c = (int)((k / plane) & 7);
+    E v = a[k];
+    if (c == 1) { const E w = b[k]; v = w > v ? w : v; }
+    if (c == 4) v = 0;
+    out[k] = v;
+}
+
+extern "C" int pmx_gae(const float *rewards_dev, const float *values_dev, const float *dones_dev, const float *last_value_dev,
+                       int32_t T, int32_t n, double gamma, double lam, float *adv_dev, float *ret_dev, void *stream)
+{
+    if (!rewards_dev || !values_dev || !dones_dev || !last_value_dev || !adv_dev || !ret_dev || T < 1 || n < 1) return PMX_ERR_INVALID;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (n >= 2048 || T < 128)
+        hipLaunchKernelGGL(pmx_gae_lane_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rewards_dev, values_dev, dones_dev,
+                           last_value_dev, T, n, gamma, lam, adv_dev, ret_dev);
+    else
+        hipLaunchKernelGGL(pmx_gae_wave_kernel, dim3(n), dim3(64), 0, st, rewards_dev, values_dev, dones_dev, last_value_dev, T, n,
+                           gamma, lam, adv_dev, ret_dev);
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
+
+// forced variants for tests / benchmarks: mode 0 = lane-per-series, 1 = wave-per-series
+extern "C" int pmx_gae_mode(const float *rewards_dev, const float *values_dev, const float *dones_dev, const float *last_value_dev,
+                            int32_t T, int32_t n, double gamma, double lam, float *adv_dev, float *ret_dev, int mode, void *stream)
+{
+    if (T < 1 || n < 1) return PMX_ERR_INVALID;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (mode == 0)
+        hipLaunchKernelGGL(pmx_gae_lane_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rewards_dev, values_dev, dones_dev,
+                           last_value_dev, T, n, gamma, lam, adv_dev, ret_dev);
+    else
+        hipLaunchKernelGGL(pmx_gae_wave_kernel, dim3(n), dim3(64), 0, st, rewards_dev, values_dev, dones_dev, last_value_dev, T, n,
+                           gamma, lam, adv_dev, ret_dev);
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
+
+extern "C" int pmx_canonicalize_obs(const void *in_dev, void *out_dev, int32_t n, int32_t H, int32_t W, int32_t obs_dtype,
+                                    void *stream)
+{
+    if (!in_dev || !out_dev || n < 0 || H < 1 || W < 1) return PMX_ERR_INVALID;
+    const long total = (long)n * 8 * H * W;
+    if (total == 0) return PMX_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    switch (obs_dtype) {
+    case PMX_OBS_F32: hipLaunchKernelGGL(pmx_canon_kernel<uint32_t>, grid, block, 0, st, (const uint32_t *)in_dev, (uint32_t *)out_dev, total, H, W); break;
+    case PMX_OBS_BF16: hipLaunchKernelGGL(pmx_canon_kernel<uint16_t>, grid, block, 0, st, (const uint16_t *)in_dev, (uint16_t *)out_dev, total, H, W); break;
+    case PMX_OBS_U8: hipLaunchKernelGGL(pmx_canon_kernel<uint8_t>, grid, block, 0, st, (const uint8_t *)in_dev, (uint8_t *)out_dev, total, H, W); break;
+    default: return PMX_ERR_INVALID;
+    }
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
+
+extern "C" int pmx_merge_obs(const void *a_dev, const void *b_dev, void *out_dev, int32_t n, int32_t H, int32_t W, int32_t obs_dtype,
+                             void *stream)
+{
+    if (!a_dev || !b_dev || !out_dev || n < 0 || H < 1 || W < 1) return PMX_ERR_INVALID;
+    const long total = (long)n * 8 * H * W;
+    if (total == 0) return PMX_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    switch (obs_dtype) {
+    case PMX_OBS_F32: hipLaunchKernelGGL(pmx_merge_kernel<uint32_t>, grid, block, 0, st, (const uint32_t *)a_dev, (const uint32_t *)b_dev, (uint32_t *)out_dev, total, H * W); break;
+    case PMX_OBS_BF16: hipLaunchKernelGGL(pmx_merge_kernel<uint16_t>, grid, block, 0, st, (const uint16_t *)a_dev, (const uint16_t *)b_dev, (uint16_t *)out_dev, total, H * W); break;
+    case PMX_OBS_U8: hipLaunchKernelGGL(pmx_merge_kernel<uint8_t>, grid, block, 0, st, (const uint8_t *)a_dev, (const uint8_t *)b_dev, (uint8_t *)out_dev, total, H * W); break;
+    default: return PMX_ERR_INVALID;
+    }
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}

@@ -1,0 +1,91 @@
+"""CPU suite: the C-ABI library loads and exports every symbol include/pmx.h declares; host-side logic
+(layout parsing, legal-list order) matches the fixtures.  No compute calls are made without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import _golden as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "pmx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pmx_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import pmx
+    lib = pmx._lib.load()
+    names = _declared()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/pmx.h but not exported by libpmx_hip.so"
+    bound = {n for n, _, _ in pmx._lib.PROTOTYPES}
+    assert set(names) == bound, f"binding and header disagree: {set(names) ^ bound}"
+    assert lib.pmx_version() == 1
+
+
+def test_struct_layouts_match_header():
+    import pmx
+    L = pmx._lib
+    # pmx_state: 8+4+4+4+8+8+128+128+4+4
+    assert C.sizeof(L.State) == 300
+    assert C.sizeof(L.StepOut) == 6 * C.sizeof(C.c_void_p)
+    assert L.Config.n_envs.offset == 8 + 4 * C.sizeof(C.c_void_p)
+
+
+def test_argument_errors_without_gpu():
+    import pmx
+    lib = pmx._lib.load()
+    assert lib.pmx_create(None, None) == -1
+    assert b"null" in lib.pmx_last_error()
+    assert lib.pmx_obs_shape(None, None, None, None, None) == -1
+
+
+@pytest.mark.parametrize("name,starts,food", [
+    ("tinyCapture", [(8, 1), (12, 1), (9, 1), (13, 1)], 22),
+    ("smallCapture", [(5, 1), (8, 9), (5, 9), (8, 1)], 28),
+    ("bloxCapture", [(1, 18), (18, 18), (1, 1), (18, 1)], 74),
+])
+def test_layout_files(name, starts, food):
+    import pmx
+    lay = pmx.get_layout(name)
+    assert lay.agent_positions == starts          # SURVEY appendix A (verified against the reference)
+    assert lay.total_food == food
+    assert lay.capsules == []
+
+
+def test_layout_rows_match_fixture_initial_state():
+    import pmx
+    for name in G.names("traj_*.npz"):
+        d, meta = G.load(name)
+        lay = pmx.Layout.from_text(meta["layout"])
+        assert (lay.food_rows == d["init_food"]).all()
+        assert (lay.cap_rows == d["init_caps"]).all()
+        assert (lay.starts == d["init_pos"]).all()
+        walls = d["init_obs"][0, 0]                # plane 0 = walls[y][x]
+        for y in range(lay.height):
+            for x in range(lay.width):
+                assert lay.is_wall(x, y) == bool(walls[y, x])
+
+
+def test_legal_list_order():
+    import pmx
+    d, meta = G.load("traj_small_uniform.npz")
+    for t, lists in enumerate(meta["legal_lists_first_ticks"]):
+        for i in range(4):
+            assert pmx.legal_list(d["legal"][t, i]) == lists[i]
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "pacman-marl-2025_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle" not in txt.lower() or f == "README.md", f"{f} mentions the oracle"

@@ -1,0 +1,379 @@
+"""GPU parity tests proper: the HIP path (through the C ABI, via pmx.PmxVecEnv) against
+  (a) the committed golden fixtures captured from the reference, and
+  (b) the CPU oracle on identical seeded inputs,
+bit-exact for every integer/byte/index output and for the float64 rewards.  Nothing here reads /root/reference."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import _golden as G
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _pmx():
+    import pmx
+    return pmx
+
+
+def _state_tuple(s, H):
+    return (tuple((s.pos[i][0], s.pos[i][1]) for i in range(4)), tuple(s.dir), tuple(s.pac), tuple(s.scared),
+            tuple(s.carry), tuple(s.ret), tuple(s.food[:H]), tuple(s.caps[:H]), s.score, s.steps)
+
+
+def _ostate_to_pmx(pmx, p, H):
+    return pmx.make_state([(p.pos[i][0], p.pos[i][1]) for i in range(4)], p.dir, p.pac, p.scared, p.carry, p.ret,
+                          p.food, p.caps, p.score, p.steps, H)
+
+
+# ------------------------------------------------------------------------------------------------ golden replay
+@pytest.mark.parametrize("name", G.names("traj_*.npz"))
+def test_golden_trajectory(name):
+    """Every env of a 96-env batch replays the recorded action stream; all outputs must equal the reference's."""
+    pmx = _pmx()
+    d, meta = G.load(name)
+    N = 96
+    lay = pmx.Layout.from_text(meta["layout"])
+    env = pmx.PmxVecEnv(lay, N, length=meta["length"], reward_forLegalAction=meta["legal_reward"],
+                        defenceReward=meta["defence"], auto_reset=False)
+    H = lay.height
+    obs, legal = env.reset()
+    assert (obs.cpu().numpy() == d["init_obs"].astype(np.float32)[None]).all()
+    assert (legal.cpu().numpy() == d["init_legal"][None]).all()
+    T = len(d["actions"])
+    for t in range(T):
+        a = torch.tensor(d["actions"][t], dtype=torch.int8).repeat(N, 1).cuda()
+        obs, rew, done, info = env.step(a)
+        o = obs.cpu().numpy()
+        assert (o == d["obs"][t].astype(np.float32)[None]).all(), f"{name} t={t} obs"
+        r = rew.cpu().numpy()
+        assert r.tobytes() == np.repeat(d["reward"][t][None], N, 0).tobytes(), f"{name} t={t} reward {r[0]} vs {d['reward'][t]}"
+        assert (done.cpu().numpy() == d["done"][t]).all(), f"{name} t={t} done"
+        assert (info["legal_actions"].cpu().numpy() == d["legal"][t][None]).all(), f"{name} t={t} legal"
+        assert (info["score_change"].cpu().numpy() == d["score_change"][t]).all()
+        assert (info["score"].cpu().numpy() == d["sub_score"][t, 3]).all()
+        if t % 37 == 0 or d["resets"][t]:
+            st = env.get_state(0, 2)
+            for s in st:
+                assert tuple((s.pos[i][0], s.pos[i][1]) for i in range(4)) == tuple(map(tuple, d["sub_pos"][t, 3]))
+                assert tuple(s.food[:H]) == tuple(d["sub_food"][t, 3]) and tuple(s.caps[:H]) == tuple(d["sub_caps"][t, 3])
+                assert tuple(s.carry) == tuple(d["sub_carry"][t, 3]) and tuple(s.ret) == tuple(d["sub_ret"][t, 3])
+                assert tuple(s.scared) == tuple(d["sub_scared"][t, 3]) and tuple(s.dir) == tuple(d["sub_dir"][t, 3])
+                assert tuple(s.pac) == tuple(d["sub_pac"][t, 3])
+        if d["resets"][t]:
+            env.reset()
+    env.close()
+
+
+@pytest.mark.parametrize("name", G.names("scen_*.npz"))
+def test_golden_scenarios(name):
+    """All K hand-built / randomised states of a fixture are loaded into a K-env batch and advanced one tick."""
+    pmx = _pmx()
+    d, meta = G.load(name)
+    K = len(d["actions"])
+    lay = pmx.Layout.from_text(meta["layout"])
+    H = lay.height
+    env = pmx.PmxVecEnv(lay, K, length=meta["length"], reward_forLegalAction=meta["legal_reward"],
+                        defenceReward=meta["defence"], auto_reset=False)
+    states = [pmx.make_state(d["in_pos"][k], d["in_dir"][k], d["in_pac"][k], d["in_scared"][k], d["in_carry"][k],
+                             d["in_ret"][k], d["in_food"][k], d["in_caps"][k], d["in_score"][k], d["in_steps"][k], H)
+              for k in range(K)]
+    env.set_state(states)
+    back = env.get_state()
+    for k in range(0, K, 17):
+        assert _state_tuple(back[k], H) == _state_tuple(states[k], H)
+    obs, rew, done, info = env.step(torch.tensor(d["actions"], dtype=torch.int8).cuda())
+    o = obs.cpu().numpy()
+    bad = np.nonzero((o != d["obs"].astype(np.float32)).reshape(K, -1).any(1))[0]
+    assert len(bad) == 0, f"{name}: obs differ for scenarios {bad[:10]} {[meta['names'][b] for b in bad[:5]]}"
+    r = rew.cpu().numpy()
+    badr = np.nonzero((r.view(np.uint64) != d["reward"].view(np.uint64)).any(1))[0]
+    assert len(badr) == 0, f"{name}: rewards differ for {badr[:10]}: {r[badr[:3]]} vs {d['reward'][badr[:3]]}"
+    assert (done.cpu().numpy() == d["done"]).all()
+    assert (info["legal_actions"].cpu().numpy() == d["legal"]).all()
+    assert (info["score_change"].cpu().numpy() == d["score_change"]).all()
+    st = env.get_state()
+    for k in range(K):
+        s = st[k]
+        tag = f"{name} k={k} {meta['names'][k]}"
+        assert tuple((s.pos[i][0], s.pos[i][1]) for i in range(4)) == tuple(map(tuple, d["sub_pos"][k, 3])), tag
+        assert tuple(s.food[:H]) == tuple(d["sub_food"][k, 3]), tag
+        assert tuple(s.caps[:H]) == tuple(d["sub_caps"][k, 3]), tag
+        assert tuple(s.carry) == tuple(d["sub_carry"][k, 3]) and tuple(s.ret) == tuple(d["sub_ret"][k, 3]), tag
+        assert tuple(s.scared) == tuple(d["sub_scared"][k, 3]) and tuple(s.pac) == tuple(d["sub_pac"][k, 3]), tag
+        assert tuple(s.dir) == tuple(d["sub_dir"][k, 3]) and s.score == d["sub_score"][k, 3], tag
+        assert s.steps == d["in_steps"][k] + 1, tag
+    env.close()
+
+
+# ------------------------------------------------------------------------------------- differential vs the oracle
+def _seed_states(pmx, env, orc, fixture, H):
+    """Start the batch from the fixture's randomised states (cycled) so that collisions/returns happen early."""
+    d, _ = G.load(fixture)
+    K = len(d["actions"])
+    N = env.n_envs
+    states = []
+    for e in range(N):
+        k = e % K
+        if e % 5 == 4:
+            states.append(None)  # keep the initial state
+            continue
+        states.append(pmx.make_state(d["in_pos"][k], d["in_dir"][k], d["in_pac"][k], d["in_scared"][k], d["in_carry"][k],
+                                     d["in_ret"][k], d["in_food"][k], d["in_caps"][k], d["in_score"][k],
+                                     min(int(d["in_steps"][k]), 250), H))
+    cur = env.get_state()
+    full = [states[e] if states[e] is not None else cur[e] for e in range(N)]
+    env.set_state(full)
+    for e in range(N):
+        s = full[e]
+        p = O.PState()
+        for i in range(4):
+            p.pos[i][0], p.pos[i][1] = s.pos[i][0], s.pos[i][1]
+            p.dir[i], p.pac[i], p.scared[i], p.carry[i], p.ret[i] = s.dir[i], s.pac[i], s.scared[i], s.carry[i], s.ret[i]
+        for y in range(H):
+            p.food[y], p.caps[y] = s.food[y], s.caps[y]
+        p.score, p.steps = s.score, s.steps
+        orc.set_state(e, p)
+
+
+@pytest.mark.parametrize("layname,fixture,N,T,dtype", [
+    ("small", "scen_small_random.npz", 2048, 330, "float32"),
+    ("tiny", "scen_tiny_random.npz", 1024, 200, "uint8"),
+    ("maze23", "scen_maze23_random.npz", 1024, 200, "bfloat16"),
+    ("blox", "scen_blox_random.npz", 512, 120, "float32"),
+])
+def test_differential_vs_oracle(layname, fixture, N, T, dtype):
+    pmx = _pmx()
+    _, meta = G.load(fixture)
+    rows = meta["layout"]
+    lay = pmx.Layout.from_text(rows)
+    H, W = lay.height, lay.width
+    length = 300
+    env = pmx.PmxVecEnv(lay, N, length=length, auto_reset=True, obs_dtype=dtype)
+    orc = O.BatchEnv(rows, N, length=length, auto_reset=True)
+    env.reset()
+    _seed_states(pmx, env, orc, fixture, H)
+    rng = np.random.RandomState(5)
+    oobs = np.zeros((N, 4, 8, H, W), np.float32)
+    legal = np.stack([[orc.lib.orc_legal(orc.L.buf, C.byref(orc.S, e * orc.ssz), i) for i in range(4)] for e in range(N)]).astype(np.uint8)
+    n_done = 0
+    for t in range(T):
+        # 70 % legal-uniform, 30 % anything (incl. illegal and out-of-range codes)
+        a = rng.randint(0, 5, size=(N, 4)).astype(np.int8)
+        pick = rng.rand(N, 4) < 0.7
+        for _ in range(3):
+            ill = pick & (((legal >> np.clip(a, 0, 4)) & 1) == 0)
+            a[ill] = rng.randint(0, 5, size=int(ill.sum()))
+        a[rng.rand(N, 4) < 0.01] = rng.choice([-1, 5, 7, 127, -128])
+        orc.tick(a, oobs)
+        obs, rew, done, info = env.step(torch.tensor(a).cuda())
+        torch.cuda.synchronize()
+        assert rew.cpu().numpy().tobytes() == orc.reward.tobytes(), f"t={t} reward"
+        assert (done.cpu().numpy() == orc.done).all(), f"t={t} done"
+        assert (info["legal_actions"].cpu().numpy() == orc.legal).all(), f"t={t} legal"
+        assert (info["score_change"].cpu().numpy() == orc.score_change).all(), f"t={t} score_change"
+        o = obs.float().cpu().numpy()
+        bad = np.nonzero((o != oobs).reshape(N, -1).any(1))[0]
+        assert len(bad) == 0, f"t={t}: obs differ for envs {bad[:10]}"
+        legal = orc.legal.copy()
+        n_done += int(orc.done.sum())
+        if t % 50 == 49:
+            st = env.get_state()
+            for e in range(0, N, 7):
+                assert _state_tuple(st[e], H) == _state_tuple(orc.get_state(e), H), f"t={t} env={e}"
+    assert n_done > 0
+    env.close()
+
+
+# ------------------------------------------------------------------------------------------ API-level behaviour
+def test_step_agent_equals_step():
+    pmx = _pmx()
+    _, meta = G.load("scen_small_random.npz")
+    lay = pmx.Layout.from_text(meta["layout"])
+    N, H = 512, lay.height
+    a_env = pmx.PmxVecEnv(lay, N, length=40, auto_reset=False)
+    b_env = pmx.PmxVecEnv(lay, N, length=40, auto_reset=False)
+    orc = O.BatchEnv(meta["layout"], N, length=40, auto_reset=False)
+    _seed_states(pmx, a_env, orc, "scen_small_random.npz", H)
+    b_env.set_state(a_env.get_state())
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for t in range(45):
+        a = torch.randint(0, 5, (N, 4), generator=g, device="cuda", dtype=torch.int8)
+        obs, rew, done, info = a_env.step(a)
+        sub = [b_env.step_agent(i, a[:, i].contiguous()).clone() for i in range(4)]
+        for i in range(4):
+            assert torch.equal(sub[i], obs[:, i]), (t, i)
+        assert torch.equal(b_env.reward, rew) and torch.equal(b_env.done, done)
+        assert torch.equal(b_env.legal, info["legal_actions"]) and torch.equal(b_env.score_change, info["score_change"])
+    with pytest.raises(pmx.PmxError):
+        b_env.step_agent(2, a[:, 2].contiguous())   # sub-steps must come in order 0,1,2,3
+    a_env.close(); b_env.close()
+
+
+def test_reset_mask_observe_and_subset():
+    pmx = _pmx()
+    lay = pmx.get_layout("tinyCapture")
+    N = 300   # not a multiple of 64/128/256: tail handling
+    env = pmx.PmxVecEnv(lay, N, length=20, auto_reset=False)
+    sub = pmx.PmxVecEnv(lay, N, length=20, auto_reset=False, obs_agents=(1, 3), obs_dtype="uint8")
+    g = torch.Generator(device="cuda").manual_seed(9)
+    init_obs = env.reset()[0].clone()
+    for t in range(10):
+        a = torch.randint(0, 5, (N, 4), generator=g, device="cuda", dtype=torch.int8)
+        obs, *_ = env.step(a)
+        sobs, *_ = sub.step(a)
+        assert sobs.shape == (N, 2, 8, lay.height, lay.width)
+        assert torch.equal(sobs.float(), obs[:, [1, 3]])
+    stepped = env.observe()[0].clone()
+    # observe() = encode the final state for all agents: agent 3's planes of the last step saw that state
+    assert torch.equal(stepped[:, 3], obs[:, 3])
+    mask = torch.zeros(N, dtype=torch.uint8, device="cuda")
+    mask[::3] = 1
+    o2, _ = env.reset(mask)
+    assert torch.equal(o2[::3], init_obs[::3])
+    keep = torch.ones(N, dtype=torch.bool); keep[::3] = False
+    assert torch.equal(o2[keep], stepped[keep])
+    env.close(); sub.close()
+
+
+def test_auto_reset_returns_fresh_observations():
+    pmx = _pmx()
+    lay = pmx.get_layout("smallCapture")
+    N = 256
+    env = pmx.PmxVecEnv(lay, N, length=5, auto_reset=True)
+    init = env.reset()[0][0].clone()
+    a = torch.full((N, 4), 4, dtype=torch.int8, device="cuda")
+    for t in range(6):
+        obs, rew, done, info = env.step(a)
+        assert int(done.sum()) == (N if t == 5 else 0)     # length + 1 ticks (gymPacMan.py:268 before :189)
+    assert torch.equal(obs, init[None].expand_as(obs))
+    st = env.get_state(0, 3)
+    assert all(s.steps == 0 and s.score == 0 for s in st)
+    env.close()
+
+
+def test_invalid_layouts_raise():
+    pmx = _pmx()
+    rows = ["%%%%%%%%%%", "%1 .  . 2%", "%3      4%", "%%%%%%%%%%"]
+    pmx.PmxVecEnv(pmx.Layout.from_text(rows), 4).close()
+    bad_border = ["%%%%%%%%%%", "%1 .  . 2 ", "%3      4%", "%%%%%%%%%%"]
+    with pytest.raises(pmx.PmxError):
+        pmx.PmxVecEnv(pmx.Layout.from_text(bad_border), 4)
+    swapped = ["%%%%%%%%%%", "%2 .  . 1%", "%3      4%", "%%%%%%%%%%"]
+    with pytest.raises(pmx.PmxError):
+        pmx.PmxVecEnv(pmx.Layout.from_text(swapped), 4)
+
+
+# --------------------------------------------------------------------------------- full-size, size-independent
+@pytest.mark.parametrize("layname,N", [("smallCapture", 16384), ("tinyCapture", 4096)])
+def test_full_size_properties(layname, N):
+    """BASELINE.json sizes.  Properties that need no reference at that size:
+       replication (the same action stream in every 64-env tile gives identical results), pellet conservation
+       (food on board + carried + returned == layout total), and observation/state consistency."""
+    pmx = _pmx()
+    lay = pmx.get_layout(layname)
+    H, W = lay.height, lay.width
+    env = pmx.PmxVecEnv(lay, N, length=300, auto_reset=True)
+    env.reset()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    tile = 64
+    walls = torch.tensor([[(int(lay.wall_rows[y]) >> x) & 1 for x in range(W)] for y in range(H)], dtype=torch.float32).cuda()
+    for t in range(330):
+        a_tile = torch.randint(0, 5, (tile, 4), generator=g, device="cuda", dtype=torch.int8)
+        a = a_tile.repeat(N // tile, 1)
+        obs, rew, done, info = env.step(a)
+        v = obs.view(N // tile, tile, 4, 8, H, W)
+        assert torch.equal(v, v[:1].expand_as(v)), f"t={t}: tiles diverged"
+        assert torch.equal(rew.view(N // tile, tile, 2), rew[:tile][None].expand(N // tile, tile, 2))
+        if t % 25 == 0:
+            assert torch.equal(obs[:, :, 0], walls[None, None].expand(N, 4, H, W))
+            self_plane = obs[:, :, 1]
+            assert torch.equal((self_plane > 0).sum((-1, -2)), torch.ones(N, 4, device="cuda", dtype=torch.long))
+            food_cells = (obs[:, 3, 6] + obs[:, 3, 7]).sum((-1, -2))
+            carry = torch.stack([obs[:, i, 1].amax((-1, -2)) - 1 for i in range(4)], 1)
+            st = env.get_state(0, 64)
+            for e in range(64):
+                s = st[e]
+                onboard = sum(bin(s.food[y]).count("1") for y in range(H))
+                assert onboard == int(food_cells[e].item())
+                assert onboard + sum(s.carry) + sum(s.ret) == lay.total_food, f"t={t} env={e}: pellets not conserved"
+                assert int(carry[e, 3].item()) == s.carry[3]
+    env.close()
+
+
+# ------------------------------------------------------------------------------------------- other kernels
+@pytest.mark.parametrize("lay", ["tiny", "small", "blox", "maze23"])
+def test_maze_distances_golden(lay):
+    pmx = _pmx()
+    d, meta = G.load(f"dist_{lay}.npz")
+    env = pmx.PmxVecEnv(pmx.Layout.from_text(meta["layout"]), 1)
+    cells, dist = env.maze_distances()
+    assert (cells.cpu().numpy() == d["cells"]).all()
+    assert (dist.cpu().numpy() == d["dist"]).all()
+    env.close()
+
+
+def _gae(mode, rew, val, done, last, gamma, lam):
+    pmx = _pmx()
+    lib = pmx._lib.load()
+    T, n = rew.shape
+    adv = torch.empty_like(rew); ret = torch.empty_like(rew)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if mode is None:
+        rc = lib.pmx_gae(rew.data_ptr(), val.data_ptr(), done.data_ptr(), last.data_ptr(), T, n, gamma, lam, adv.data_ptr(), ret.data_ptr(), st)
+    else:
+        rc = lib.pmx_gae_mode(rew.data_ptr(), val.data_ptr(), done.data_ptr(), last.data_ptr(), T, n, gamma, lam, adv.data_ptr(), ret.data_ptr(), mode, st)
+    assert rc == 0
+    return adv, ret
+
+
+def test_gae_golden_bit_exact_and_wave_scan():
+    d, meta = G.load("gae.npz")
+    for c in meta["cases"]:
+        rew = torch.tensor(d[c + "_rew"]).cuda()[:, None].contiguous()
+        val = torch.tensor(d[c + "_val"]).cuda()[:, None].contiguous()
+        done = torch.tensor(d[c + "_done"]).cuda()[:, None].contiguous()
+        last = torch.tensor([float(d[c + "_last"])], dtype=torch.float32).cuda()
+        adv, ret = _gae(0, rew, val, done, last, meta["gamma"], meta["lam"])
+        assert adv[:, 0].cpu().numpy().tobytes() == d[c + "_adv"].tobytes(), c      # lane kernel: bit-exact
+        assert ret[:, 0].cpu().numpy().tobytes() == d[c + "_ret"].tobytes(), c
+        adv2, ret2 = _gae(1, rew, val, done, last, meta["gamma"], meta["lam"])      # wave scan: re-associated floats
+        scale = float(np.abs(d[c + "_adv"]).max()) + 1.0
+        assert float((adv2[:, 0].cpu() - torch.tensor(d[c + "_adv"])).abs().max()) <= 1e-5 * scale, c
+        assert float((ret2[:, 0].cpu() - torch.tensor(d[c + "_ret"])).abs().max()) <= 1e-5 * scale, c
+
+
+def test_gae_batched_vs_oracle():
+    rng = np.random.RandomState(0)
+    T, n = 32, 4096
+    rew = rng.randn(T, n).astype(np.float32); val = rng.randn(T, n).astype(np.float32)
+    done = (rng.rand(T, n) < 0.05).astype(np.float32); last = rng.randn(n).astype(np.float32)
+    adv, ret = _gae(None, torch.tensor(rew).cuda(), torch.tensor(val).cuda(), torch.tensor(done).cuda(), torch.tensor(last).cuda(), 0.99, 0.95)
+    adv, ret = adv.cpu().numpy(), ret.cpu().numpy()
+    for i in range(0, n, 97):
+        a, r = O.gae(rew[:, i], val[:, i], done[:, i], float(last[i]), 0.99, 0.95)
+        assert a.tobytes() == adv[:, i].tobytes() and r.tobytes() == ret[:, i].tobytes()
+
+
+def test_canonicalize_merge_golden():
+    pmx = _pmx()
+    lib = pmx._lib.load()
+    d, meta = G.load("shaping.npz")
+    tr, _ = G.load(meta["traj"])
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for code, dt in ((0, torch.float32), (1, torch.bfloat16), (2, torch.uint8)):
+        for j, t in enumerate(d["ticks"]):
+            o = torch.tensor(tr["obs"][t]).cuda().to(dt).contiguous()      # [4,8,H,W]
+            H, W = o.shape[-2:]
+            canon = torch.empty_like(o)
+            assert lib.pmx_canonicalize_obs(o.data_ptr(), canon.data_ptr(), 4, H, W, code, st) == 0
+            assert (canon.float().cpu().numpy() == d["canon_red"][j]).all()
+            mb = torch.empty_like(o[0])
+            assert lib.pmx_merge_obs(o[1].data_ptr(), o[3].data_ptr(), mb.data_ptr(), 1, H, W, code, st) == 0
+            assert (mb.float().cpu().numpy() == d["merged_blue"][j]).all()
+            mr = torch.empty_like(o[0])
+            assert lib.pmx_merge_obs(canon[0].data_ptr(), canon[2].data_ptr(), mr.data_ptr(), 1, H, W, code, st) == 0
+            assert (mr.float().cpu().numpy() == d["merged_red"][j]).all()
