@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the batched Capture-the-Flag tick on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload small16384|tiny4096|blox4096] [--obs float32|bfloat16|uint8]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch: one gymPacMan tick (4 agent sub-steps, rewards, termination,
+4 observation tensors, auto-reset) of every env on the rank's GPU.  Inputs (the action stream) are resident in HBM
+before the timed region.  Envs are independent, so N GPUs hold N disjoint shards ("weak" scaling, no data-path
+collective); the timed region is bracketed by barrier + synchronize and the reported time is the max over ranks.
+
+The JSON line also carries
+  roofline      the observation-expansion kernel (>95 % of the bytes): algorithmic bytes per launch / its average
+                duration measured with HIP events on the launch stream (pmx_profile_begin/end) vs the 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (a port of the reference's tick, oracle/pmx_oracle.c) on one host core, bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    "small16384": ("smallCapture", 16384),   # BASELINE.json configs[2]: the layout the metric is quoted on
+    "tiny4096": ("tinyCapture", 4096),       # configs[1]
+    "blox4096": ("bloxCapture", 4096),       # the layout the reference actually trains on (20x20)
+}
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy ceiling)
+ELEM = {"float32": 4, "bfloat16": 2, "uint8": 1}
+
+
+def algorithmic_bytes(H, W, e, n_obs=4):
+    """B = 2*S + 41 + n_obs*8*H*W*e, S = 4*H + 48 (packed state, read and written once)."""
+    S = 4 * H + 8 + 32 + 8
+    return 2 * S + 41 + n_obs * 8 * H * W * e
+
+
+def cpu_baseline(layout_rows, length, seconds=12.0):
+    """Times the oracle port on ONE host core on a bounded sample of the same workload (256 envs, f32 planes)."""
+    from oracle import oracle as O
+    n = 256
+    env = O.BatchEnv(layout_rows, n, length=length, auto_reset=True)
+    rng = np.random.RandomState(0)
+    acts = rng.randint(0, 5, size=(64, n, 4)).astype(np.int8)
+    obs = np.zeros((n, 4, 8, env.L.H, env.L.W), np.float32)
+    for k in range(5):
+        env.tick(acts[k], obs)
+    t0 = time.perf_counter()
+    ticks = 0
+    while True:
+        for k in range(16):
+            env.tick(acts[(ticks + k) % 64], obs)
+        ticks += 16
+        if time.perf_counter() - t0 > seconds:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n * ticks / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n} envs x {ticks} ticks of the same layout, float32 planes, auto-reset, uniform random actions "
+                      f"({dt:.1f} s on 1 of {os.cpu_count()} host cores)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="small16384", choices=sorted(WORKLOADS))
+    ap.add_argument("--envs", type=int, default=0, help="override envs per GPU")
+    ap.add_argument("--obs", default="float32", choices=sorted(ELEM))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import pmx
+    layname, n_envs = WORKLOADS[args.workload]
+    if args.envs:
+        n_envs = args.envs
+    lay = pmx.get_layout(layname)
+    H, W = lay.height, lay.width
+    length = 300
+    dev = torch.device("cuda", local)
+    env = pmx.PmxVecEnv(lay, n_envs, length=length, auto_reset=True, obs_dtype=args.obs, device=dev)
+    env.reset()
+    # the action stream: uniform over the 5 actions from the device Philox generator, resident before timing
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    n_act = 64
+    actions = torch.randint(0, 5, (n_act, n_envs, 4), generator=g, device=dev, dtype=torch.int8)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for k in range(args.warmup):
+        env.step(actions[k % n_act])
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        env.step(actions[k % n_act])
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    checksum = int(env.obs.sum(dtype=torch.float64).item()) if args.obs != "uint8" else int(env.obs.sum().item())
+
+    # second pass, same K steps, with HIP events around each kernel launch: per-kernel durations for the roofline
+    env.profile_begin(args.steps + 8)
+    for k in range(args.steps):
+        env.step(actions[k % n_act])
+    prof = env.profile_end()
+    e = ELEM[args.obs]
+    expand_bytes = n_envs * 4 * 8 * H * W * e                      # algorithmic bytes of one expansion launch
+    expand_s = prof["expand_ms"] / 1e3 / max(prof["expand_launches"], 1)
+    rule_s = prof["rule_ms"] / 1e3 / max(prof["rule_launches"], 1)
+    achieved = expand_bytes / expand_s / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            key = f"{args.workload}:{args.obs}"
+            traffic = tj.get(key, {}).get("expand_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        B = algorithmic_bytes(H, W, e)
+        value = world * n_envs * args.steps / dt
+        line = {
+            "metric": "env-steps/s (4-agent smallCapture)" if layname == "smallCapture" else f"env-steps/s (4-agent {layname})",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"{layname}.lay 2v2, {n_envs} envs/GPU, gymPacMan tick (self_play), length {length}, "
+                                   f"auto-reset, uniform random actions (Philox seed 1234), 4 observations/env-tick",
+                       "envs_per_gpu": n_envs, "layout": layname, "obs_dtype": args.obs, "obs_bytes_per_elem": e,
+                       "parallelism": f"env-sharded x{world}, no data-path collective"},
+            "agent_steps_per_s": 4 * value,
+            "algorithmic_bytes_per_env_step": B,
+            "tick_GBps": value / world * B / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "pmx_expand_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": expand_bytes, "avg_launch_us": expand_s * 1e6,
+                         "launches": prof["expand_launches"], "rule_kernel_avg_us": rule_s * 1e6},
+            "obs_checksum": checksum,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(lay.text, length)
+        print(json.dumps(line))
+    env.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

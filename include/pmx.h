@@ -135,6 +135,12 @@ int pmx_set_state(pmx_env *env, int32_t first, int32_t count, const pmx_state *s
  * output available on return (the count is computed on the host); dist_dev may be NULL to query it. */
 int pmx_maze_distances(pmx_env *env, int8_t *cells_dev, uint8_t *dist_dev, int32_t *n_cells, void *stream);
 
+/* Measurement hooks (no reference counterpart): between begin and end, every tick records a HIP event pair around
+ * its rule-kernel and its expansion-kernel launch on the caller's stream; end synchronises them and returns the
+ * summed kernel durations (milliseconds) and launch counts.  bench.py's roofline figures come from here. */
+int pmx_profile_begin(pmx_env *env, int32_t max_launches);
+int pmx_profile_end(pmx_env *env, double *rule_ms, int32_t *rule_launches, double *expand_ms, int32_t *expand_launches);
+
 /* pacman_mappo_resnet.compute_gae (pacman_mappo_resnet.py:277-290) for n independent series laid out
  * [T][n] (time-major): rewards/values/dones float32, last_value [n] float32; adv/ret [T][n] float32. */
 int pmx_gae(const float *rewards_dev, const float *values_dev, const float *dones_dev, const float *last_value_dev,

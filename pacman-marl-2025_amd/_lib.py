@@ -49,6 +49,8 @@ PROTOTYPES = [
     ("pmx_get_state", C.c_int, [_VP, _I32, _I32, C.POINTER(State), _VP]),
     ("pmx_set_state", C.c_int, [_VP, _I32, _I32, C.POINTER(State), _VP]),
     ("pmx_maze_distances", C.c_int, [_VP, _VP, _VP, C.POINTER(_I32), _VP]),
+    ("pmx_profile_begin", C.c_int, [_VP, _I32]),
+    ("pmx_profile_end", C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(_I32), C.POINTER(C.c_double), C.POINTER(_I32)]),
     ("pmx_gae", C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, C.c_double, C.c_double, _VP, _VP, _VP]),
     ("pmx_canonicalize_obs", C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _VP]),
     ("pmx_merge_obs", C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),

@@ -29,6 +29,10 @@ struct pmx_env {
     int open_agent;            // next agent expected by pmx_step_agent
     std::vector<int8_t> cells; // open cells in asList(False) order
     std::vector<int16_t> cell_index;
+    // optional per-kernel timing (pmx_profile_begin/end): pairs of events around each launch
+    bool profiling;
+    std::vector<hipEvent_t> ev_rule, ev_expand;
+    size_t ev_rule_used, ev_expand_used;
 };
 
 namespace {
@@ -101,6 +105,18 @@ void fill_tick_params(pmx_env *env, PmxTickParams &p, const int8_t *actions, con
     }
 }
 
+// when profiling, returns the pair of events to record around the next launch of that kernel (or nullptr)
+hipEvent_t *prof_pair(pmx_env *env, bool expand)
+{
+    if (!env->profiling) return nullptr;
+    std::vector<hipEvent_t> &v = expand ? env->ev_expand : env->ev_rule;
+    size_t &used = expand ? env->ev_expand_used : env->ev_rule_used;
+    if (used + 2 > v.size()) return nullptr;
+    hipEvent_t *p = &v[used];
+    used += 2;
+    return p;
+}
+
 int launch_expand(pmx_env *env, void *obs, bool from_snapshots, int single_agent, hipStream_t st)
 {
     PmxExpandParams x;
@@ -119,7 +135,10 @@ int launch_expand(pmx_env *env, void *obs, bool from_snapshots, int single_agent
         x.n_emit = env->n_emit;
         for (int i = 0; i < 4; ++i) x.emit[i] = env->emit[i];
     }
+    hipEvent_t *ev = prof_pair(env, true);
+    if (ev) HIP_TRY(hipEventRecord(ev[0], st));
     HIP_TRY(pmx_launch_expand(&x, env->cfg.obs_dtype, st));
+    if (ev) HIP_TRY(hipEventRecord(ev[1], st));
     return PMX_OK;
 }
 
@@ -207,6 +226,7 @@ int pmx_create(const pmx_config *cfg, pmx_env **out)
                 env->cells.push_back((int8_t)y);
             }
     env->lay_dev = nullptr; env->dump_dev = nullptr; env->state_dev = nullptr; env->snap_dev = nullptr;
+    env->profiling = false; env->ev_rule_used = env->ev_expand_used = 0;
 
     hipError_t e = hipSetDevice(cfg->device);
     const size_t N = (size_t)cfg->n_envs;
@@ -234,6 +254,8 @@ int pmx_destroy(pmx_env *env)
     if (env->dump_dev) (void)hipFree(env->dump_dev);
     if (env->state_dev) (void)hipFree(env->state_dev);
     if (env->snap_dev) (void)hipFree(env->snap_dev);
+    for (hipEvent_t e : env->ev_rule) (void)hipEventDestroy(e);
+    for (hipEvent_t e : env->ev_expand) (void)hipEventDestroy(e);
     delete env;
     return PMX_OK;
 }
@@ -267,7 +289,10 @@ int pmx_step(pmx_env *env, const int8_t *actions_dev, const pmx_step_out *out, v
     if (env->open_agent != 0) return fail(PMX_ERR_INVALID, "pmx_step: a tick opened with pmx_step_agent is unfinished");
     PmxTickParams p;
     fill_tick_params(env, p, actions_dev, out);
+    hipEvent_t *ev = prof_pair(env, false);
+    if (ev) HIP_TRY(hipEventRecord(ev[0], as_stream(stream)));
     HIP_TRY(pmx_launch_rule(&p, env->lay.H, as_stream(stream)));
+    if (ev) HIP_TRY(hipEventRecord(ev[1], as_stream(stream)));
     if (out && out->obs_dev) return launch_expand(env, out->obs_dev, true, -1, as_stream(stream));
     return PMX_OK;
 }
@@ -296,6 +321,52 @@ int pmx_observe(pmx_env *env, void *obs_dev, uint8_t *legal_dev, void *stream)
         HIP_TRY(pmx_launch_reset(&p, env->lay.H, as_stream(stream)));
     }
     if (obs_dev) return launch_expand(env, obs_dev, false, -1, as_stream(stream));
+    return PMX_OK;
+}
+
+// ---- per-kernel timing for bench.py (not part of the reference surface) -----------------------------------------
+// Between begin and end every pmx_step / pmx_observe / pmx_reset records a HIP event pair around its rule-kernel and
+// expansion-kernel launches, on the stream the kernels run on.  pmx_profile_end synchronises those events and returns
+// the summed kernel durations in milliseconds and the launch counts.
+int pmx_profile_begin(pmx_env *env, int32_t max_launches)
+{
+    if (!env || max_launches < 1) return fail(PMX_ERR_INVALID, "pmx_profile_begin: bad argument");
+    auto grow = [&](std::vector<hipEvent_t> &v) -> hipError_t {
+        while (v.size() < (size_t)max_launches * 2) {
+            hipEvent_t e;
+            hipError_t rc = hipEventCreate(&e);
+            if (rc != hipSuccess) return rc;
+            v.push_back(e);
+        }
+        return hipSuccess;
+    };
+    HIP_TRY(grow(env->ev_rule));
+    HIP_TRY(grow(env->ev_expand));
+    env->ev_rule_used = env->ev_expand_used = 0;
+    env->profiling = true;
+    return PMX_OK;
+}
+
+int pmx_profile_end(pmx_env *env, double *rule_ms, int32_t *rule_launches, double *expand_ms, int32_t *expand_launches)
+{
+    if (!env) return fail(PMX_ERR_INVALID, "null env");
+    env->profiling = false;
+    auto sum = [&](std::vector<hipEvent_t> &v, size_t used, double *ms, int32_t *n) -> hipError_t {
+        double acc = 0.0;
+        for (size_t k = 0; k + 1 < used; k += 2) {
+            hipError_t rc = hipEventSynchronize(v[k + 1]);
+            if (rc != hipSuccess) return rc;
+            float t = 0.f;
+            rc = hipEventElapsedTime(&t, v[k], v[k + 1]);
+            if (rc != hipSuccess) return rc;
+            acc += t;
+        }
+        if (ms) *ms = acc;
+        if (n) *n = (int32_t)(used / 2);
+        return hipSuccess;
+    };
+    HIP_TRY(sum(env->ev_rule, env->ev_rule_used, rule_ms, rule_launches));
+    HIP_TRY(sum(env->ev_expand, env->ev_expand_used, expand_ms, expand_launches));
     return PMX_OK;
 }
 

@@ -143,6 +143,16 @@ class PmxVecEnv:
                                             self._stream()), "pmx_observe")
         return self.obs, self.legal
 
+    # -- measurement ---------------------------------------------------------------------------------------------
+    def profile_begin(self, max_launches):
+        _lib.check(self.lib.pmx_profile_begin(self.handle, int(max_launches)), "pmx_profile_begin")
+
+    def profile_end(self):
+        """-> dict(rule_ms, rule_launches, expand_ms, expand_launches): summed kernel times from HIP events."""
+        rm, em, rn, en = C.c_double(), C.c_double(), C.c_int32(), C.c_int32()
+        _lib.check(self.lib.pmx_profile_end(self.handle, C.byref(rm), C.byref(rn), C.byref(em), C.byref(en)), "pmx_profile_end")
+        return dict(rule_ms=rm.value, rule_launches=rn.value, expand_ms=em.value, expand_launches=en.value)
+
     # -- state exchange ------------------------------------------------------------------------------------------
     def get_state(self, first=0, count=None):
         count = self.n_envs - first if count is None else count

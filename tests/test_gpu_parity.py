@@ -259,7 +259,7 @@ def test_invalid_layouts_raise():
     pmx = _pmx()
     rows = ["%%%%%%%%%%", "%1 .  . 2%", "%3      4%", "%%%%%%%%%%"]
     pmx.PmxVecEnv(pmx.Layout.from_text(rows), 4).close()
-    bad_border = ["%%%%%%%%%%", "%1 .  . 2 ", "%3      4%", "%%%%%%%%%%"]
+    bad_border = ["%%%%%%%%%%", "%1 .  . 2.", "%3      4%", "%%%%%%%%%%"]
     with pytest.raises(pmx.PmxError):
         pmx.PmxVecEnv(pmx.Layout.from_text(bad_border), 4)
     swapped = ["%%%%%%%%%%", "%2 .  . 1%", "%3      4%", "%%%%%%%%%%"]
