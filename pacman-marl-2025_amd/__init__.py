@@ -5,6 +5,7 @@ the repo root)."""
 from . import _lib
 from ._lib import PmxError
 from .layout import Layout, get_layout
+from . import maze_generator
 from .vec_env import PmxVecEnv, legal_list, make_state
 
 __all__ = ["PmxError", "Layout", "get_layout", "PmxVecEnv", "legal_list", "make_state"]
