@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define PMX_BLOCK 256            // 4 wavefronts of 64
+#define PMX_BLOCK 256            // expansion kernel: 4 wavefronts of 64
+#ifndef PMX_RULE_BLOCK
+#define PMX_RULE_BLOCK 64        // rule kernels: one wavefront per block, so that N/64 blocks spread over all CUs
+#endif
 #define PMX_SCARED_TIME 40       // capture.py:75
 #define PMX_MIN_FOOD 2           // capture.py:70
 

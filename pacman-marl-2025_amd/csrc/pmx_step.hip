@@ -10,6 +10,8 @@
 //                      This kernel moves >95 % of the bytes of the tick and is the HBM-roofline kernel.
 // The split keeps the divergent integer rule logic at 64 envs per wave while the byte-heavy expansion gets
 // N*4 wavefronts of perfectly coalesced stores regardless of N.
+#include <cstdlib>
+
 #include "pmx_device.h"
 
 namespace {
@@ -27,7 +29,7 @@ struct Acc {
 
 struct Ctx {
     const uint32_t *wl;   // LDS: wall rows of the layout
-    uint32_t *fd;         // LDS: this lane's food column, row y at fd[y * PMX_BLOCK]
+    uint32_t *fd;         // LDS: this lane's food column, row y at fd[y * PMX_RULE_BLOCK]
     const PmxLayoutDev *L;
     const int8_t *dump;
     int W, H, half, n_dump;
@@ -88,7 +90,7 @@ __device__ __forceinline__ void dump_food(Env &e, const Ctx &c, int who_x, int w
         int X = who_x + c.dump[2 * k], Y = who_y + c.dump[2 * k + 1];
         if (X <= 0 || Y <= 0 || X >= c.W || Y >= c.H) continue;          // :609
         if ((c.wl[Y] >> X) & 1u) continue;                                // :612
-        uint32_t row = c.fd[Y * PMX_BLOCK];
+        uint32_t row = c.fd[Y * PMX_RULE_BLOCK];
         if ((row >> X) & 1u) continue;                                    // :614
         if ((2 * X < c.W) != side_red) continue;                          // :618
         if (cap_find(e, X, Y) >= 0) continue;                             // :621
@@ -96,7 +98,7 @@ __device__ __forceinline__ void dump_food(Env &e, const Ctx &c, int who_x, int w
 #pragma unroll
         for (int i = 0; i < 4; ++i) occ |= (e.x[i] == X && e.y[i] == Y);
         if (occ) continue;
-        c.fd[Y * PMX_BLOCK] = row | (1u << X);
+        c.fd[Y * PMX_RULE_BLOCK] = row | (1u << X);
         --num;
         if (X < c.half) ++d_red; else ++d_blue;
     }
@@ -113,12 +115,12 @@ __device__ __forceinline__ void kill_dump(Env &e, const Ctx &c, int &d_red, int 
 template <bool RED>
 __device__ __forceinline__ void consume(Env &e, const Ctx &c, int px, int py, int &d_red, int &d_blue)
 {
-    uint32_t row = c.fd[py * PMX_BLOCK];
+    uint32_t row = c.fd[py * PMX_RULE_BLOCK];
     if ((row >> px) & 1u) {
         constexpr int T1 = RED ? 0 : 1, T2 = T1 + 2;                      // :533-537 team order
         if (e.x[T1] == px && e.y[T1] == py) e.carry[T1] += 1;
         else if (e.x[T2] == px && e.y[T2] == py) e.carry[T2] += 1;
-        c.fd[py * PMX_BLOCK] = row & ~(1u << px);
+        c.fd[py * PMX_RULE_BLOCK] = row & ~(1u << px);
         if (px < c.half) --d_red; else --d_blue;
     }
     int slot = cap_find(e, px, py);
@@ -212,7 +214,7 @@ __device__ __forceinline__ void tick_substep(Env &e, Acc &a, const Ctx &c, int a
 
 __device__ __forceinline__ void load_env(Env &e, const Ctx &c, const uint32_t *st, int N, int env)
 {
-    for (int y = 0; y < c.H; ++y) c.fd[y * PMX_BLOCK] = st[(size_t)y * N + env];
+    for (int y = 0; y < c.H; ++y) c.fd[y * PMX_RULE_BLOCK] = st[(size_t)y * N + env];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         unpack_a(e, i, st[(size_t)PMX_W_AGENT_A(c.H, i) * N + env]);
@@ -227,7 +229,7 @@ __device__ __forceinline__ void load_env(Env &e, const Ctx &c, const uint32_t *s
 // first PMX_SNAP_WORDS words (food, agents, capsules)
 __device__ __forceinline__ void store_snapshot(const Env &e, const Ctx &c, uint32_t *st, int N, int env)
 {
-    for (int y = 0; y < c.H; ++y) st[(size_t)y * N + env] = c.fd[y * PMX_BLOCK];
+    for (int y = 0; y < c.H; ++y) st[(size_t)y * N + env] = c.fd[y * PMX_RULE_BLOCK];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         st[(size_t)PMX_W_AGENT_A(c.H, i) * N + env] = pack_a(e, i);
@@ -247,7 +249,7 @@ __device__ __forceinline__ void store_env(const Env &e, const Ctx &c, uint32_t *
 // game.py:490-508 GameStateData.initialize + gymPacMan.py:94 steps = 0
 __device__ __forceinline__ void init_env(Env &e, const Ctx &c)
 {
-    for (int y = 0; y < c.H; ++y) c.fd[y * PMX_BLOCK] = c.L->food0[y];
+    for (int y = 0; y < c.H; ++y) c.fd[y * PMX_RULE_BLOCK] = c.L->food0[y];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         e.x[i] = c.L->startx[i]; e.y[i] = c.L->starty[i]; e.dir[i] = 4;
@@ -264,7 +266,7 @@ __device__ __forceinline__ void tick_finish(Env &e, Acc &a, const Ctx &c, const 
     double red_r = a.red_r + (double)(a.red_sc > 0 ? a.red_sc : 0);
     int n_red = 0, n_blue = 0;                                            // capture.py:332-342 halfGrid sums
     for (int y = 0; y < c.H; ++y) {
-        uint32_t row = c.fd[y * PMX_BLOCK];
+        uint32_t row = c.fd[y * PMX_RULE_BLOCK];
         n_red += __popc(row & c.L->lo_mask);
         n_blue += __popc(row & c.L->hi_mask);
     }
@@ -310,12 +312,12 @@ __device__ __forceinline__ Ctx make_ctx(const PmxTickParams &p, uint32_t *lds)
 
 }  // namespace
 
-// dynamic LDS: 32 wall rows + H food rows x PMX_BLOCK lanes
-extern "C" __global__ __launch_bounds__(PMX_BLOCK) void pmx_rule_kernel(PmxTickParams p)
+// dynamic LDS: 32 wall rows + H food rows x PMX_RULE_BLOCK lanes
+extern "C" __global__ __launch_bounds__(PMX_RULE_BLOCK) void pmx_rule_kernel(PmxTickParams p)
 {
     extern __shared__ uint32_t lds[];
     Ctx c = make_ctx(p, lds);
-    const int env = blockIdx.x * PMX_BLOCK + threadIdx.x;
+    const int env = blockIdx.x * PMX_RULE_BLOCK + threadIdx.x;
     if (env >= p.N) return;
     Env e;
     load_env(e, c, p.state, p.N, env);
@@ -338,7 +340,7 @@ template <int I>
 __device__ __forceinline__ void rule_agent_body(const PmxTickParams &p, uint32_t *lds)
 {
     Ctx c = make_ctx(p, lds);
-    const int env = blockIdx.x * PMX_BLOCK + threadIdx.x;
+    const int env = blockIdx.x * PMX_RULE_BLOCK + threadIdx.x;
     if (env >= p.N) return;
     Env e;
     load_env(e, c, p.state, p.N, env);
@@ -360,7 +362,7 @@ __device__ __forceinline__ void rule_agent_body(const PmxTickParams &p, uint32_t
     store_env(e, c, p.state, p.N, env);
 }
 
-extern "C" __global__ __launch_bounds__(PMX_BLOCK) void pmx_rule_agent_kernel(PmxTickParams p, int agent)
+extern "C" __global__ __launch_bounds__(PMX_RULE_BLOCK) void pmx_rule_agent_kernel(PmxTickParams p, int agent)
 {
     extern __shared__ uint32_t lds[];
     switch (agent) {   // wave-uniform
@@ -372,11 +374,11 @@ extern "C" __global__ __launch_bounds__(PMX_BLOCK) void pmx_rule_agent_kernel(Pm
 }
 
 // gymPacMan.reset (gymPacMan.py:92-141) for the masked envs; legal masks for all envs if requested
-extern "C" __global__ __launch_bounds__(PMX_BLOCK) void pmx_reset_kernel(PmxTickParams p)
+extern "C" __global__ __launch_bounds__(PMX_RULE_BLOCK) void pmx_reset_kernel(PmxTickParams p)
 {
     extern __shared__ uint32_t lds[];
     Ctx c = make_ctx(p, lds);
-    const int env = blockIdx.x * PMX_BLOCK + threadIdx.x;
+    const int env = blockIdx.x * PMX_RULE_BLOCK + threadIdx.x;
     if (env >= p.N) return;
     Env e;
     if (!p.no_reset && (!p.reset_mask || p.reset_mask[env])) {
@@ -445,74 +447,90 @@ __device__ __forceinline__ uint4 pack_obs(uint64_t s, int dself, uint32_t carry)
     return o;
 }
 
-template <int DT>
+// VAR bit 0: non-temporal stores; bit 1: persistent blocks (grid-stride over envs)
+template <int DT, int VAR>
 __global__ __launch_bounds__(PMX_BLOCK) void pmx_expand_kernel(PmxExpandParams p)
 {
     constexpr int VEC = ObsVec<DT>::VEC;
+    constexpr bool NT = (VAR & 1) != 0;
     __shared__ uint32_t tab[4][8 * 32 + 8];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const PmxLayoutDev *L = p.lay;
     const int W = L->W, H = L->H;
-    const long total = (long)p.N * p.n_emit;
-    long blk = blockIdx.x;
-    if (p.n_emit == 4 && (p.N & 127) == 0) {
-        // XCD-aware order: blocks b, b+8, b+16.. share an XCD (and its L2); give each XCD 16 consecutive envs so that
-        // the SoA snapshot words it reads come from the same 64-byte lines.
-        long g = blk >> 7, r = blk & 127;
-        blk = (g << 7) + ((r & 7) << 4) + (r >> 3);
-    }
-    const long q = blk * 4 + wave;
-    const bool active = q < total;
-    const long env = active ? q / p.n_emit : 0;
-    const int slot = active ? (int)(q - env * p.n_emit) : 0;
-    const int agent = p.single_agent >= 0 ? p.single_agent : p.emit[slot];
-    const uint32_t *S = p.snap[agent] + env;
-    const size_t N = (size_t)p.N;
-    uint32_t *T = tab[wave];
-
-    for (int r = H + lane; r < 6 * H; r += 64) T[r] = 0;
-    if (lane < 4) T[8 * H + lane] = 0;
-    if (active && lane < H) {
-        uint32_t f = S[(size_t)lane * N];
-        T[lane] = L->walls[lane];
-        T[6 * H + lane] = f & L->hi_mask;       // blue food: x >= int(W/2) (capture.py:336)
-        T[7 * H + lane] = f & L->lo_mask;       // red food
-    }
-    __syncthreads();
-    if (active && lane < 4) {
-        uint32_t a = S[(size_t)PMX_W_AGENT_A(H, lane) * N];
-        int x = a & 0xFF, y = (a >> 8) & 0xFF;
-        int plane = lane == agent ? 1 : (((lane ^ agent) == 2) ? 4 : 5);   // gymPacMan.py:205-215
-        atomicOr(&T[plane * H + y], 1u << x);
-    } else if (active && lane < 8) {
-        int j = lane - 4;
-        uint32_t w = S[(size_t)PMX_W_CAPS(H, j >> 1) * N];
-        uint32_t cxy = (w >> (16 * (j & 1))) & 0xFFFFu;
-        if (cxy != 0xFFFFu) {
-            int x = cxy & 0xFF, y = cxy >> 8;
-            int plane = (2 * x > W) ? 2 : 3;                                // halfList: blue x > W/2, red x <= W/2
-            atomicOr(&T[plane * H + y], 1u << x);
-        }
-    }
-    const uint32_t a_self = active ? S[(size_t)PMX_W_AGENT_A(H, agent) * N] : 0;
-    const uint32_t b_self = active ? S[(size_t)PMX_W_AGENT_B(H, agent) * N] : 0;
-    const uint32_t carry = (b_self >> 8) & 0xFFF;
-    const int fself = (H + (int)((a_self >> 8) & 0xFF)) * W + (int)(a_self & 0xFF);
-    __syncthreads();
-    if (!active) return;
-
-    const int n_vec = 8 * H * W / VEC;
     const uint32_t mul = L->div_mul;
-    uint4 *out = reinterpret_cast<uint4 *>(p.obs) + (size_t)q * n_vec;
-    for (int k = lane; k < n_vec; k += 64) {
-        const uint32_t e0 = (uint32_t)k * VEC;
-        const uint32_t r0 = (e0 * mul) >> 20;
-        const int x0 = (int)(e0 - r0 * W);
-        const uint32_t m0 = T[r0], m1 = T[r0 + 1], m2 = T[r0 + 2];
-        int sh2 = 2 * W - x0; sh2 = sh2 > 63 ? 63 : sh2;
-        const uint64_t s = (uint64_t)(m0 >> x0) | ((uint64_t)m1 << (W - x0)) | ((uint64_t)m2 << sh2);
-        out[k] = pack_obs<DT>(s, fself - (int)e0, carry);
+    const uint32_t hi_mask = L->hi_mask, lo_mask = L->lo_mask;
+    const long total = (long)p.N * p.n_emit;
+    const long n_blocks = (total + 3) / 4;
+    const size_t N = (size_t)p.N;
+    const int n_vec = 8 * H * W / VEC;
+    uint32_t *T = tab[wave];
+    const uint32_t wall_row = lane < H ? L->walls[lane] : 0u;
+    const bool remap = p.n_emit == 4 && (p.N & 127) == 0;
+
+    for (long blk0 = blockIdx.x; blk0 < n_blocks; blk0 += gridDim.x) {
+        long blk = blk0;
+        if (remap) {
+            // XCD-aware order: blocks b, b+8, b+16.. share an XCD (and its L2); give each XCD 16 consecutive envs so
+            // that the SoA snapshot words it reads come from the same 64-byte lines.
+            long g = blk >> 7, r = blk & 127;
+            blk = (g << 7) + ((r & 7) << 4) + (r >> 3);
+        }
+        const long q = blk * 4 + wave;
+        const bool active = q < total;
+        const long env = active ? q / p.n_emit : 0;
+        const int slot = active ? (int)(q - env * p.n_emit) : 0;
+        const int agent = p.single_agent >= 0 ? p.single_agent : p.emit[slot];
+        const uint32_t *S = p.snap[agent] + env;
+
+        for (int r = H + lane; r < 6 * H; r += 64) T[r] = 0;
+        if (lane < 4) T[8 * H + lane] = 0;
+        if (active && lane < H) {
+            uint32_t f = S[(size_t)lane * N];
+            T[lane] = wall_row;
+            T[6 * H + lane] = f & hi_mask;          // blue food: x >= int(W/2) (capture.py:336)
+            T[7 * H + lane] = f & lo_mask;          // red food
+        }
+        __syncthreads();
+        if (active && lane < 4) {
+            uint32_t a = S[(size_t)PMX_W_AGENT_A(H, lane) * N];
+            int x = a & 0xFF, y = (a >> 8) & 0xFF;
+            int plane = lane == agent ? 1 : (((lane ^ agent) == 2) ? 4 : 5);   // gymPacMan.py:205-215
+            atomicOr(&T[plane * H + y], 1u << x);
+        } else if (active && lane < 8) {
+            int j = lane - 4;
+            uint32_t w = S[(size_t)PMX_W_CAPS(H, j >> 1) * N];
+            uint32_t cxy = (w >> (16 * (j & 1))) & 0xFFFFu;
+            if (cxy != 0xFFFFu) {
+                int x = cxy & 0xFF, y = cxy >> 8;
+                int plane = (2 * x > W) ? 2 : 3;                                // halfList: blue x > W/2, red x <= W/2
+                atomicOr(&T[plane * H + y], 1u << x);
+            }
+        }
+        const uint32_t a_self = active ? S[(size_t)PMX_W_AGENT_A(H, agent) * N] : 0;
+        const uint32_t b_self = active ? S[(size_t)PMX_W_AGENT_B(H, agent) * N] : 0;
+        const uint32_t carry = (b_self >> 8) & 0xFFF;
+        const int fself = (H + (int)((a_self >> 8) & 0xFF)) * W + (int)(a_self & 0xFF);
+        __syncthreads();
+        if (active) {
+            uint4 *out = reinterpret_cast<uint4 *>(p.obs) + (size_t)q * n_vec;
+            for (int k = lane; k < n_vec; k += 64) {
+                const uint32_t e0 = (uint32_t)k * VEC;
+                const uint32_t r0 = (e0 * mul) >> 20;
+                const int x0 = (int)(e0 - r0 * W);
+                const uint32_t m0 = T[r0], m1 = T[r0 + 1], m2 = T[r0 + 2];
+                int sh2 = 2 * W - x0; sh2 = sh2 > 63 ? 63 : sh2;
+                const uint64_t s = (uint64_t)(m0 >> x0) | ((uint64_t)m1 << (W - x0)) | ((uint64_t)m2 << sh2);
+                const uint4 v = pack_obs<DT>(s, fself - (int)e0, carry);
+                if (NT) {
+                    __builtin_nontemporal_store(v.x, &out[k].x); __builtin_nontemporal_store(v.y, &out[k].y);
+                    __builtin_nontemporal_store(v.z, &out[k].z); __builtin_nontemporal_store(v.w, &out[k].w);
+                } else {
+                    out[k] = v;
+                }
+            }
+        }
+        if (VAR & 2) __syncthreads();   // the next iteration rewrites T
     }
 }
 
@@ -521,36 +539,47 @@ __global__ __launch_bounds__(PMX_BLOCK) void pmx_expand_kernel(PmxExpandParams p
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" hipError_t pmx_launch_rule(const PmxTickParams *p, int H, hipStream_t st)
 {
-    const int blocks = (p->N + PMX_BLOCK - 1) / PMX_BLOCK;
-    const size_t lds = (32 + (size_t)H * PMX_BLOCK) * sizeof(uint32_t);
-    hipLaunchKernelGGL(pmx_rule_kernel, dim3(blocks), dim3(PMX_BLOCK), lds, st, *p);
+    const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
+    const size_t lds = (32 + (size_t)H * PMX_RULE_BLOCK) * sizeof(uint32_t);
+    hipLaunchKernelGGL(pmx_rule_kernel, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p);
     return hipGetLastError();
 }
 
 extern "C" hipError_t pmx_launch_rule_agent(const PmxTickParams *p, int H, int agent, hipStream_t st)
 {
-    const int blocks = (p->N + PMX_BLOCK - 1) / PMX_BLOCK;
-    const size_t lds = (32 + (size_t)H * PMX_BLOCK) * sizeof(uint32_t);
-    hipLaunchKernelGGL(pmx_rule_agent_kernel, dim3(blocks), dim3(PMX_BLOCK), lds, st, *p, agent);
+    const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
+    const size_t lds = (32 + (size_t)H * PMX_RULE_BLOCK) * sizeof(uint32_t);
+    hipLaunchKernelGGL(pmx_rule_agent_kernel, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p, agent);
     return hipGetLastError();
 }
 
 extern "C" hipError_t pmx_launch_reset(const PmxTickParams *p, int H, hipStream_t st)
 {
-    const int blocks = (p->N + PMX_BLOCK - 1) / PMX_BLOCK;
-    const size_t lds = (32 + (size_t)H * PMX_BLOCK) * sizeof(uint32_t);
-    hipLaunchKernelGGL(pmx_reset_kernel, dim3(blocks), dim3(PMX_BLOCK), lds, st, *p);
+    const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
+    const size_t lds = (32 + (size_t)H * PMX_RULE_BLOCK) * sizeof(uint32_t);
+    hipLaunchKernelGGL(pmx_reset_kernel, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p);
     return hipGetLastError();
 }
 
 extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, int dtype, hipStream_t st)
 {
     const long waves = (long)p->N * p->n_emit;
-    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    unsigned blocks = (unsigned)((waves + 3) / 4);
+    static const int variant = getenv("PMX_EXPAND_VARIANT") ? atoi(getenv("PMX_EXPAND_VARIANT")) : 0;
+    static const int pblocks = getenv("PMX_EXPAND_BLOCKS") ? atoi(getenv("PMX_EXPAND_BLOCKS")) : 2048;
+    if ((variant & 2) && blocks > (unsigned)pblocks) blocks = (unsigned)pblocks;
+#define PMX_EXPAND_CASE(DT, V) hipLaunchKernelGGL((pmx_expand_kernel<DT, V>), dim3(blocks), dim3(PMX_BLOCK), 0, st, *p)
+#define PMX_EXPAND_DT(DT)                                                                                    \
+    switch (variant & 3) {                                                                                   \
+    case 0: PMX_EXPAND_CASE(DT, 0); break;                                                                   \
+    case 1: PMX_EXPAND_CASE(DT, 1); break;                                                                   \
+    case 2: PMX_EXPAND_CASE(DT, 2); break;                                                                   \
+    default: PMX_EXPAND_CASE(DT, 3); break;                                                                  \
+    }
     switch (dtype) {
-    case 0: hipLaunchKernelGGL(pmx_expand_kernel<0>, dim3(blocks), dim3(PMX_BLOCK), 0, st, *p); break;
-    case 1: hipLaunchKernelGGL(pmx_expand_kernel<1>, dim3(blocks), dim3(PMX_BLOCK), 0, st, *p); break;
-    default: hipLaunchKernelGGL(pmx_expand_kernel<2>, dim3(blocks), dim3(PMX_BLOCK), 0, st, *p); break;
+    case 0: PMX_EXPAND_DT(0); break;
+    case 1: PMX_EXPAND_DT(1); break;
+    default: PMX_EXPAND_DT(2); break;
     }
     return hipGetLastError();
 }
