@@ -198,9 +198,9 @@ int pmx_create(const pmx_config *cfg, pmx_env **out)
                         i, red ? "red" : "blue");
         L.startx[i] = sx; L.starty[i] = sy;
     }
-    L.div_mul = ((1u << 20) + W - 1) / W;
-    for (uint32_t e = 0; e < (uint32_t)(8 * H * W); ++e)
-        if (((e * L.div_mul) >> 20) != e / W) return fail(PMX_ERR_UNSUPPORTED, "internal: reciprocal for width %d inexact", W);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x)
+            if ((L.walls[y] >> x) & 1u) L.wall_stream[(y * W + x) >> 5] |= 1u << ((y * W + x) & 31);
     const std::vector<int8_t> dump = dump_order(std::max(W, H));
     L.n_dump = (int)(dump.size() / 2);
 

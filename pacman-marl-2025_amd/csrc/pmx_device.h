@@ -41,7 +41,7 @@ struct PmxLayoutDev {
     int32_t startx[4], starty[4];
     int32_t total_food;
     int32_t n_dump;              // entries of the dump-order table
-    uint32_t div_mul;            // e / W == (e * div_mul) >> 20 for every element index e < 8*H*W
+    uint32_t wall_stream[32];    // plane 0 of the observation as a packed bit stream: bit (y*W + x) = wall
 };
 
 struct PmxTickParams {

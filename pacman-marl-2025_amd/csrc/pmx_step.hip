@@ -10,8 +10,6 @@
 //                      This kernel moves >95 % of the bytes of the tick and is the HBM-roofline kernel.
 // The split keeps the divergent integer rule logic at 64 envs per wave while the byte-heavy expansion gets
 // N*4 wavefronts of perfectly coalesced stores regardless of N.
-#include <cstdlib>
-
 #include "pmx_device.h"
 
 namespace {
@@ -396,141 +394,144 @@ extern "C" __global__ __launch_bounds__(PMX_RULE_BLOCK) void pmx_reset_kernel(Pm
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Observation expansion (gymPacMan.py:195-229).  One wavefront per (env, emitted agent).
-//   1. the wave builds a row table T[8*H] in LDS: one 32-bit mask per (plane, y) row of the output;
-//      planes 0, 6, 7 are whole rows (walls, food & blue half, food & red half), planes 1..5 are points
-//      (self, capsules, ally, enemies) OR-ed in by 8 lanes;
-//   2. every lane then produces 16 contiguous output bytes per iteration from a 64-bit window of the row-major
-//      bit stream and stores them with one dwordx4 store: the wave writes 1 KiB of consecutive addresses per
-//      instruction.
-// ---------------------------------------------------------------------------------------------------------------
 template <int DT> struct ObsVec;
 template <> struct ObsVec<0> { static constexpr int VEC = 4; };    // float32
 template <> struct ObsVec<1> { static constexpr int VEC = 8; };    // bfloat16
 template <> struct ObsVec<2> { static constexpr int VEC = 16; };   // uint8
 
+// VEC stream bits (bit j = element j of the 16-byte vector) -> the 16 bytes.  Set elements are 1 in the output type.
 template <int DT>
-__device__ __forceinline__ uint4 pack_obs(uint64_t s, int dself, uint32_t carry)
+__device__ __forceinline__ uint4 pack_obs(uint32_t bits)
 {
-    uint4 o;
+    uint32_t w[4];
     if (DT == 0) {
-        uint32_t w[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            w[j] = ((uint32_t)(s >> j) & 1u) * 0x3F800000u;
-            if (dself == j) w[j] = __float_as_uint((float)(1 + carry));
-        }
-        o = make_uint4(w[0], w[1], w[2], w[3]);
+        for (int j = 0; j < 4; ++j) w[j] = (uint32_t)__builtin_amdgcn_sbfe((int)bits, j, 1) & 0x3F800000u;
     } else if (DT == 1) {
-        uint32_t w[4];
-        const uint32_t selfbits = __float_as_uint((float)(1 + carry)) >> 16;   // exact for 1+carry <= 256
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint32_t lo = ((uint32_t)(s >> (2 * k)) & 1u) * 0x3F80u;
-            uint32_t hi = ((uint32_t)(s >> (2 * k + 1)) & 1u) * 0x3F80u;
-            if (dself == 2 * k) lo = selfbits;
-            if (dself == 2 * k + 1) hi = selfbits;
-            w[k] = lo | (hi << 16);
-        }
-        o = make_uint4(w[0], w[1], w[2], w[3]);
+        for (int k = 0; k < 4; ++k)
+            w[k] = ((uint32_t)__builtin_amdgcn_sbfe((int)bits, 2 * k, 1) & 0x3F80u) |
+                   ((uint32_t)__builtin_amdgcn_sbfe((int)bits, 2 * k + 1, 1) & 0x3F800000u);
     } else {
-        uint32_t w[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint32_t nib = (uint32_t)(s >> (4 * k)) & 0xFu;
-            w[k] = (nib * 0x00204081u) & 0x01010101u;               // bit j -> byte j
-            if ((dself >> 2) == k && dself >= 0) w[k] += carry << (8 * (dself & 3));
-        }
-        o = make_uint4(w[0], w[1], w[2], w[3]);
+        for (int k = 0; k < 4; ++k) w[k] = (((bits >> (4 * k)) & 0xFu) * 0x00204081u) & 0x01010101u;   // bit j -> byte j
     }
-    return o;
+    return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// VAR bit 0: non-temporal stores; bit 1: persistent blocks (grid-stride over envs)
-template <int DT, int VAR>
+// the one element of plane 1 that is set holds 1 + numCarrying (gymPacMan.py:205): patch element d of the vector
+template <int DT>
+__device__ __forceinline__ void patch_self(uint4 &v, int d, uint32_t carry)
+{
+    uint32_t *w = reinterpret_cast<uint32_t *>(&v);
+    if (DT == 0) {
+        const uint32_t val = __float_as_uint((float)(1 + carry));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (d == j) w[j] = val;
+    } else if (DT == 1) {
+        const uint32_t val = __float_as_uint((float)(1 + carry)) >> 16;   // exact in bfloat16 for 1 + carry <= 256
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (d == 2 * k) w[k] = (w[k] & 0xFFFF0000u) | val;
+            if (d == 2 * k + 1) w[k] = (w[k] & 0x0000FFFFu) | (val << 16);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if ((d >> 2) == k) w[k] += carry << (8 * (d & 3));
+    }
+}
+
+// OR the W-bit row `v` into the packed bit stream at bit offset `off`
+__device__ __forceinline__ void stream_or_row(uint32_t *T, uint32_t off, uint32_t v, int W)
+{
+    if (v == 0) return;
+    const uint32_t word = off >> 5, sh = off & 31;
+    atomicOr(&T[word], v << sh);
+    if (sh + W > 32) atomicOr(&T[word + 1], v >> (32 - sh));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Observation expansion (gymPacMan.py:195-229).  One wavefront per (env, emitted agent), wavefronts independent.
+//   1. the wave assembles the PACKED bit stream of the [8][H][W] block in LDS (bit e = element e != 0): the wall
+//      plane is a per-layout constant copied from the layout record, the food planes are OR-ed in row by row
+//      (H lanes), self / ally / enemies / capsules are single bits (8 lanes);
+//   2. every lane then reads ONE aligned stream word per 16 output bytes (a 4/8/16-bit field never straddles a
+//      32-bit word), expands it and issues one non-temporal dwordx4 store: the wave writes 1 KiB of consecutive
+//      addresses per instruction.  LDS operations of one wavefront execute in order, so no barrier is needed.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DT>
 __global__ __launch_bounds__(PMX_BLOCK) void pmx_expand_kernel(PmxExpandParams p)
 {
     constexpr int VEC = ObsVec<DT>::VEC;
-    constexpr bool NT = (VAR & 1) != 0;
-    __shared__ uint32_t tab[4][8 * 32 + 8];
+    __shared__ uint32_t tab[4][8 * 32 * 32 / 32 + 8];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const PmxLayoutDev *L = p.lay;
     const int W = L->W, H = L->H;
-    const uint32_t mul = L->div_mul;
-    const uint32_t hi_mask = L->hi_mask, lo_mask = L->lo_mask;
+    const int HW = H * W;
     const long total = (long)p.N * p.n_emit;
-    const long n_blocks = (total + 3) / 4;
+    long blk = blockIdx.x;
+    if (p.n_emit == 4 && (p.N & 127) == 0) {
+        // XCD-aware order: blocks b, b+8, b+16.. share an XCD (and its L2); give each XCD 16 consecutive envs so that
+        // the SoA snapshot words it reads come from the same 64-byte lines.
+        long g = blk >> 7, r = blk & 127;
+        blk = (g << 7) + ((r & 7) << 4) + (r >> 3);
+    }
+    const long q = blk * 4 + wave;
+    if (q >= total) return;
+    const long env = q / p.n_emit;
+    const int slot = (int)(q - env * p.n_emit);
+    const int agent = p.single_agent >= 0 ? p.single_agent : p.emit[slot];
+    const uint32_t *S = p.snap[agent] + env;
     const size_t N = (size_t)p.N;
-    const int n_vec = 8 * H * W / VEC;
     uint32_t *T = tab[wave];
-    const uint32_t wall_row = lane < H ? L->walls[lane] : 0u;
-    const bool remap = p.n_emit == 4 && (p.N & 127) == 0;
 
-    for (long blk0 = blockIdx.x; blk0 < n_blocks; blk0 += gridDim.x) {
-        long blk = blk0;
-        if (remap) {
-            // XCD-aware order: blocks b, b+8, b+16.. share an XCD (and its L2); give each XCD 16 consecutive envs so
-            // that the SoA snapshot words it reads come from the same 64-byte lines.
-            long g = blk >> 7, r = blk & 127;
-            blk = (g << 7) + ((r & 7) << 4) + (r >> 3);
-        }
-        const long q = blk * 4 + wave;
-        const bool active = q < total;
-        const long env = active ? q / p.n_emit : 0;
-        const int slot = active ? (int)(q - env * p.n_emit) : 0;
-        const int agent = p.single_agent >= 0 ? p.single_agent : p.emit[slot];
-        const uint32_t *S = p.snap[agent] + env;
+    // issue the snapshot loads first, their latency hides behind the table initialisation
+    const uint32_t food = lane < H ? S[(size_t)lane * N] : 0u;
+    uint32_t pt = 0;
+    if (lane < 4) pt = S[(size_t)PMX_W_AGENT_A(H, lane) * N];
+    else if (lane < 8) pt = S[(size_t)PMX_W_CAPS(H, (lane - 4) >> 1) * N];
+    const uint32_t a_self = S[(size_t)PMX_W_AGENT_A(H, agent) * N];
+    const uint32_t b_self = S[(size_t)PMX_W_AGENT_B(H, agent) * N];
 
-        for (int r = H + lane; r < 6 * H; r += 64) T[r] = 0;
-        if (lane < 4) T[8 * H + lane] = 0;
-        if (active && lane < H) {
-            uint32_t f = S[(size_t)lane * N];
-            T[lane] = wall_row;
-            T[6 * H + lane] = f & hi_mask;          // blue food: x >= int(W/2) (capture.py:336)
-            T[7 * H + lane] = f & lo_mask;          // red food
+    const int n_words = (8 * HW + 31) >> 5;
+    const int wall_words = (HW + 31) >> 5;
+    for (int k = lane; k < n_words + 1; k += 64) T[k] = k < wall_words ? L->wall_stream[k] : 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < H) {
+        stream_or_row(T, (uint32_t)((6 * H + lane) * W), food & L->hi_mask, W);    // blue food: x >= int(W/2) (capture.py:336)
+        stream_or_row(T, (uint32_t)((7 * H + lane) * W), food & L->lo_mask, W);    // red food
+    }
+    if (lane < 4) {
+        const int x = pt & 0xFF, y = (pt >> 8) & 0xFF;
+        const int plane = lane == agent ? 1 : (((lane ^ agent) == 2) ? 4 : 5);      // gymPacMan.py:205-215
+        const uint32_t off = (uint32_t)((plane * H + y) * W + x);
+        atomicOr(&T[off >> 5], 1u << (off & 31));
+    } else if (lane < 8) {
+        const uint32_t cxy = (pt >> (16 * ((lane - 4) & 1))) & 0xFFFFu;
+        if (cxy != 0xFFFFu) {
+            const int x = cxy & 0xFF, y = cxy >> 8;
+            const int plane = (2 * x > W) ? 2 : 3;                                  // halfList: blue x > W/2, red x <= W/2
+            const uint32_t off = (uint32_t)((plane * H + y) * W + x);
+            atomicOr(&T[off >> 5], 1u << (off & 31));
         }
-        __syncthreads();
-        if (active && lane < 4) {
-            uint32_t a = S[(size_t)PMX_W_AGENT_A(H, lane) * N];
-            int x = a & 0xFF, y = (a >> 8) & 0xFF;
-            int plane = lane == agent ? 1 : (((lane ^ agent) == 2) ? 4 : 5);   // gymPacMan.py:205-215
-            atomicOr(&T[plane * H + y], 1u << x);
-        } else if (active && lane < 8) {
-            int j = lane - 4;
-            uint32_t w = S[(size_t)PMX_W_CAPS(H, j >> 1) * N];
-            uint32_t cxy = (w >> (16 * (j & 1))) & 0xFFFFu;
-            if (cxy != 0xFFFFu) {
-                int x = cxy & 0xFF, y = cxy >> 8;
-                int plane = (2 * x > W) ? 2 : 3;                                // halfList: blue x > W/2, red x <= W/2
-                atomicOr(&T[plane * H + y], 1u << x);
-            }
-        }
-        const uint32_t a_self = active ? S[(size_t)PMX_W_AGENT_A(H, agent) * N] : 0;
-        const uint32_t b_self = active ? S[(size_t)PMX_W_AGENT_B(H, agent) * N] : 0;
-        const uint32_t carry = (b_self >> 8) & 0xFFF;
-        const int fself = (H + (int)((a_self >> 8) & 0xFF)) * W + (int)(a_self & 0xFF);
-        __syncthreads();
-        if (active) {
-            uint4 *out = reinterpret_cast<uint4 *>(p.obs) + (size_t)q * n_vec;
-            for (int k = lane; k < n_vec; k += 64) {
-                const uint32_t e0 = (uint32_t)k * VEC;
-                const uint32_t r0 = (e0 * mul) >> 20;
-                const int x0 = (int)(e0 - r0 * W);
-                const uint32_t m0 = T[r0], m1 = T[r0 + 1], m2 = T[r0 + 2];
-                int sh2 = 2 * W - x0; sh2 = sh2 > 63 ? 63 : sh2;
-                const uint64_t s = (uint64_t)(m0 >> x0) | ((uint64_t)m1 << (W - x0)) | ((uint64_t)m2 << sh2);
-                const uint4 v = pack_obs<DT>(s, fself - (int)e0, carry);
-                if (NT) {
-                    __builtin_nontemporal_store(v.x, &out[k].x); __builtin_nontemporal_store(v.y, &out[k].y);
-                    __builtin_nontemporal_store(v.z, &out[k].z); __builtin_nontemporal_store(v.w, &out[k].w);
-                } else {
-                    out[k] = v;
-                }
-            }
-        }
-        if (VAR & 2) __syncthreads();   // the next iteration rewrites T
+    }
+    const uint32_t carry = (b_self >> 8) & 0xFFF;
+    const int fself = (H + (int)((a_self >> 8) & 0xFF)) * W + (int)(a_self & 0xFF);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const int n_vec = 8 * HW / VEC;
+    uint4 *out = reinterpret_cast<uint4 *>(p.obs) + (size_t)q * n_vec;
+    for (int k = lane; k < n_vec; k += 64) {
+        const uint32_t e0 = (uint32_t)k * VEC;
+        const uint32_t bits = T[e0 >> 5] >> (e0 & 31);
+        uint4 v = pack_obs<DT>(bits);
+        const uint32_t d = (uint32_t)(fself - (int)e0);
+        if (d < (uint32_t)VEC) patch_self<DT>(v, (int)d, carry);
+        __builtin_nontemporal_store(v.x, &out[k].x); __builtin_nontemporal_store(v.y, &out[k].y);
+        __builtin_nontemporal_store(v.z, &out[k].z); __builtin_nontemporal_store(v.w, &out[k].w);
     }
 }
 
@@ -564,22 +565,11 @@ extern "C" hipError_t pmx_launch_reset(const PmxTickParams *p, int H, hipStream_
 extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, int dtype, hipStream_t st)
 {
     const long waves = (long)p->N * p->n_emit;
-    unsigned blocks = (unsigned)((waves + 3) / 4);
-    static const int variant = getenv("PMX_EXPAND_VARIANT") ? atoi(getenv("PMX_EXPAND_VARIANT")) : 0;
-    static const int pblocks = getenv("PMX_EXPAND_BLOCKS") ? atoi(getenv("PMX_EXPAND_BLOCKS")) : 2048;
-    if ((variant & 2) && blocks > (unsigned)pblocks) blocks = (unsigned)pblocks;
-#define PMX_EXPAND_CASE(DT, V) hipLaunchKernelGGL((pmx_expand_kernel<DT, V>), dim3(blocks), dim3(PMX_BLOCK), 0, st, *p)
-#define PMX_EXPAND_DT(DT)                                                                                    \
-    switch (variant & 3) {                                                                                   \
-    case 0: PMX_EXPAND_CASE(DT, 0); break;                                                                   \
-    case 1: PMX_EXPAND_CASE(DT, 1); break;                                                                   \
-    case 2: PMX_EXPAND_CASE(DT, 2); break;                                                                   \
-    default: PMX_EXPAND_CASE(DT, 3); break;                                                                  \
-    }
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
     switch (dtype) {
-    case 0: PMX_EXPAND_DT(0); break;
-    case 1: PMX_EXPAND_DT(1); break;
-    default: PMX_EXPAND_DT(2); break;
+    case 0: hipLaunchKernelGGL(pmx_expand_kernel<0>, dim3(blocks), dim3(PMX_BLOCK), 0, st, *p); break;
+    case 1: hipLaunchKernelGGL(pmx_expand_kernel<1>, dim3(blocks), dim3(PMX_BLOCK), 0, st, *p); break;
+    default: hipLaunchKernelGGL(pmx_expand_kernel<2>, dim3(blocks), dim3(PMX_BLOCK), 0, st, *p); break;
     }
     return hipGetLastError();
 }
