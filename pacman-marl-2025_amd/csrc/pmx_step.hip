@@ -470,13 +470,7 @@ __global__ __launch_bounds__(PMX_BLOCK) void pmx_expand_kernel(PmxExpandParams p
     const int W = L->W, H = L->H;
     const int HW = H * W;
     const long total = (long)p.N * p.n_emit;
-    long blk = blockIdx.x;
-    if (p.n_emit == 4 && (p.N & 127) == 0) {
-        // XCD-aware order: blocks b, b+8, b+16.. share an XCD (and its L2); give each XCD 16 consecutive envs so that
-        // the SoA snapshot words it reads come from the same 64-byte lines.
-        long g = blk >> 7, r = blk & 127;
-        blk = (g << 7) + ((r & 7) << 4) + (r >> 3);
-    }
+    const long blk = blockIdx.x;
     const long q = blk * 4 + wave;
     if (q >= total) return;
     const long env = q / p.n_emit;
@@ -530,6 +524,7 @@ __global__ __launch_bounds__(PMX_BLOCK) void pmx_expand_kernel(PmxExpandParams p
         uint4 v = pack_obs<DT>(bits);
         const uint32_t d = (uint32_t)(fself - (int)e0);
         if (d < (uint32_t)VEC) patch_self<DT>(v, (int)d, carry);
+        // streaming stores: the planes are consumed by a later kernel, not re-read here (merged into one dwordx4 nt)
         __builtin_nontemporal_store(v.x, &out[k].x); __builtin_nontemporal_store(v.y, &out[k].y);
         __builtin_nontemporal_store(v.z, &out[k].z); __builtin_nontemporal_store(v.w, &out[k].w);
     }
