@@ -1,0 +1,253 @@
+"""MAPPO on the vectorised env: model, PPO loss/update, flat parameter bucket, data-parallel gradient exchange.
+
+Mirrors the training side of the reference's pacman_mappo_resnet.py for the hot path only:
+  MAPPOAgent            :97-211 (+ ResidualBlock :49-67, PositionalEncoding2D :69-95); parameter names are the
+                        reference's, so its state_dict checkpoints load unchanged
+  ppo_loss              :571-585 (per-minibatch advantage normalisation with the unbiased std, clipped surrogate,
+                        0.5*MSE value loss, entropy bonus)
+  PPOLearner.update_minibatch  :587-595 (zero_grad, backward, clip_grad_norm_ 0.5, Adam eps 1e-5, EMA 0.995)
+  canonicalize_action   :232-238
+Differences that are design, not semantics: parameters, gradients and the EMA copy live in ONE flat fp32 buffer each
+(one RCCL all-reduce per optimizer step over xGMI, one fused Adam, one lerp for the EMA); the network runs under
+bf16 autocast on the GPU (MFMA through MIOpen / hipBLASLt) with fp32 master weights; fp32 on CPU for the parity tests.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+GAMMA, GAE_LAMBDA = 0.99, 0.95                     # pacman_mappo_resnet.py:19-20
+CLIP_EPS, VF_COEF, MAX_GRAD_NORM = 0.15, 0.5, 0.5  # :21-23
+LR_START, LR_END = 2e-4, 4e-5                      # :27-28
+ENT_COEF_START, ENT_COEF_END = 0.02, 0.004         # :29-30
+EMA_DECAY = 0.995                                  # :38
+SHAPING_SCALE = 0.1                                # :34
+
+
+class ResidualBlock(nn.Module):
+    """conv3x3 - GroupNorm(4) - GELU - conv3x3 - GroupNorm(4) - (+x) - GELU   (pacman_mappo_resnet.py:49-67)"""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.conv1 = nn.Conv2d(channels, channels, 3, padding=1)
+        self.gn1 = nn.GroupNorm(4, channels)
+        self.act = nn.GELU()
+        self.conv2 = nn.Conv2d(channels, channels, 3, padding=1)
+        self.gn2 = nn.GroupNorm(4, channels)
+
+    def forward(self, x):
+        y = self.act(self.gn1(self.conv1(x)))
+        y = self.gn2(self.conv2(y))
+        return self.act(y + x)
+
+
+class PositionalEncoding2D(nn.Module):
+    """Fixed sin/cos table: first half of the channels encodes y, second half x (pacman_mappo_resnet.py:69-95)."""
+
+    def __init__(self, d_model, max_h=50, max_w=50):
+        super().__init__()
+        half = d_model // 2
+        den = torch.exp(torch.arange(0, half, 2) * -(math.log(10000.0) / half))
+
+        def table(n):
+            pos = torch.arange(n).unsqueeze(1)
+            t = torch.zeros(n, half)
+            t[:, 0::2] = torch.sin(pos * den)
+            t[:, 1::2] = torch.cos(pos * den)
+            return t
+
+        self.register_buffer("y_enc", table(max_h))
+        self.register_buffer("x_enc", table(max_w))
+
+    def forward(self, x):
+        _, _, H, W = x.shape
+        pos = torch.cat([self.y_enc[:H, None, :].expand(H, W, -1), self.x_enc[None, :W, :].expand(H, W, -1)], dim=2)
+        return x + pos.permute(2, 0, 1).unsqueeze(0).to(x.dtype)
+
+
+class MAPPOAgent(nn.Module):
+    """Actor: conv 8->16->32, three residual blocks, Linear(32*H*W -> 512), LayerNorm, GELU, Linear(512 -> 5).
+    Critic: conv 8->32 + 2-D positional encoding, 2 post-LN Transformer encoder layers (d=32, 4 heads, ff=128) over
+    the H*W tokens, mean pool, Linear 32->512->1 (pacman_mappo_resnet.py:97-170)."""
+
+    def __init__(self, obs_shape, action_dim=5, num_agents=2):
+        super().__init__()
+        self.obs_shape = tuple(obs_shape)
+        C, H, W = self.obs_shape
+        ch = 32
+        self.actor_backbone = nn.Sequential(
+            nn.Conv2d(C, 16, 3, padding=1), nn.GELU(), nn.Conv2d(16, ch, 3, padding=1), nn.GELU(),
+            ResidualBlock(ch), ResidualBlock(ch), ResidualBlock(ch), nn.Flatten())
+        self.actor_head = nn.Sequential(nn.Linear(ch * H * W, 512), nn.LayerNorm(512), nn.GELU(), nn.Linear(512, action_dim))
+        self.d_model = 32
+        self.critic_projector = nn.Sequential(nn.Conv2d(C, self.d_model, 3, padding=1))
+        self.pos_encoder = PositionalEncoding2D(self.d_model)
+        layer = nn.TransformerEncoderLayer(d_model=self.d_model, nhead=4, dim_feedforward=128, dropout=0.0, batch_first=False)
+        self.critic_transformer = nn.TransformerEncoder(layer, num_layers=2, enable_nested_tensor=False)
+        self.critic_head = nn.Sequential(nn.Linear(self.d_model, 512), nn.GELU(), nn.Linear(512, 1))
+        self.apply(self._init_weights)                                   # :149-158
+        nn.init.orthogonal_(self.actor_head[-1].weight, gain=0.01)
+        nn.init.orthogonal_(self.critic_head[-1].weight, gain=1.0)
+
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, (nn.Linear, nn.Conv2d)):
+            nn.init.orthogonal_(m.weight, gain=math.sqrt(2))
+            if m.bias is not None:
+                m.bias.data.fill_(0.0)
+
+    def logits(self, obs):
+        return self.actor_head(self.actor_backbone(obs))
+
+    def value(self, merged_obs):
+        """merged_obs [B,8,H,W] -> [B] (pacman_mappo_resnet.py:160-170)"""
+        x = self.pos_encoder(self.critic_projector(merged_obs))
+        x = x.flatten(2).permute(2, 0, 1)                                # [H*W, B, d]
+        x = self.critic_transformer(x).mean(dim=0)
+        return self.critic_head(x).squeeze(-1)
+
+    def evaluate(self, obs, merged_obs, action):
+        """-> value, log_prob, entropy  (:196-205)"""
+        # same arithmetic as torch.distributions.Categorical(logits=...): normalise with logsumexp, probs by softmax
+        logits = self.logits(obs).float()
+        norm = logits - logits.logsumexp(dim=-1, keepdim=True)
+        probs = F.softmax(norm, dim=-1)
+        logp = norm.gather(1, action.view(-1, 1)).squeeze(1)
+        ent = -(norm.clamp(min=torch.finfo(norm.dtype).min) * probs).sum(-1)
+        return self.value(merged_obs).float(), logp, ent
+
+    @torch.no_grad()
+    def act(self, obs, generator=None):
+        """Sample actions for a batch: -> action [B] int64, log_prob [B] (Categorical(logits).sample, :173-177)."""
+        logp_all = F.log_softmax(self.logits(obs).float(), dim=-1)
+        a = torch.multinomial(logp_all.exp(), 1, generator=generator).squeeze(1)
+        return a, logp_all.gather(1, a.view(-1, 1)).squeeze(1)
+
+    @torch.no_grad()
+    def get_deterministic_action(self, obs):                             # :207-211
+        return self.logits(obs).argmax(dim=-1)
+
+
+_RED_ACTION_MAP = (0, 3, 2, 1, 4)   # East <-> West for a red learner (pacman_mappo_resnet.py:232-238)
+
+
+def canonicalize_action(action, is_red_agent):
+    if not is_red_agent:
+        return action
+    if isinstance(action, torch.Tensor):
+        return torch.tensor(_RED_ACTION_MAP, device=action.device, dtype=action.dtype)[action.long()]
+    return _RED_ACTION_MAP[int(action)]
+
+
+def ppo_loss(model, obs, merged, act, old_logp, adv, ret, clip_eps, ent_coef, vf_coef=VF_COEF):
+    """The minibatch objective of pacman_mappo_resnet.py:571-585.  Returns (loss, dict of detached scalars)."""
+    vals, logp, ent = model.evaluate(obs, merged, act)
+    norm_adv = (adv - adv.mean()) / (adv.std() + 1e-8)                   # unbiased std, per minibatch (:577)
+    ratio = (logp - old_logp).exp()
+    pg = -torch.min(norm_adv * ratio, norm_adv * torch.clamp(ratio, 1 - clip_eps, 1 + clip_eps)).mean()
+    vl = 0.5 * ((vals - ret) ** 2).mean()
+    ent_mean = ent.mean()
+    loss = pg + vf_coef * vl - ent_coef * ent_mean
+    with torch.no_grad():
+        clip_frac = ((ratio - 1).abs() > clip_eps).float().mean()
+    return loss, {"pg": pg.detach(), "vl": vl.detach(), "entropy": ent_mean.detach(), "clip_frac": clip_frac,
+                  "loss": loss.detach()}
+
+
+class FlatBucket:
+    """All parameters of a module re-homed as views into one flat fp32 buffer; same for the gradients.
+    The data-parallel exchange is then ONE all-reduce of `grad` per optimizer step (2.6 M params = 10.5 MB on
+    smallCapture: latency-bound on xGMI, so one message beats many)."""
+
+    def __init__(self, module):
+        params = [p for p in module.parameters() if p.requires_grad]
+        self.numel = sum(p.numel() for p in params)
+        dev, dt = params[0].device, params[0].dtype
+        self.data = torch.empty(self.numel, device=dev, dtype=dt)
+        self.grad = torch.zeros(self.numel, device=dev, dtype=dt)
+        off = 0
+        for p in params:
+            n = p.numel()
+            self.data[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.data[off:off + n].view_as(p)
+            p.grad = self.grad[off:off + n].view_as(p)
+            off += n
+        self.params = params
+
+
+class PPOLearner:
+    """One optimizer step = ppo_loss -> backward into the flat gradient -> (all-reduce mean over ranks) -> clip by global
+    norm 0.5 -> Adam(eps 1e-5) -> EMA 0.995 (pacman_mappo_resnet.py:587-595).  Every rank ends each step with bit-identical
+    parameters because the clip and the update see the same reduced gradient."""
+
+    def __init__(self, model, lr=LR_START, process_group=None, world_size=1, autocast_dtype=None):
+        self.model = model
+        self.bucket = FlatBucket(model)
+        self.ema = self.bucket.data.clone()                              # EMA of the parameters (:365, :593-595)
+        self.exp_avg = torch.zeros_like(self.bucket.data)
+        self.exp_avg_sq = torch.zeros_like(self.bucket.data)
+        self.step_count = 0
+        self.lr = lr
+        self.betas, self.eps = (0.9, 0.999), 1e-5                        # torch.optim.Adam defaults, eps from :366
+        self.pg = process_group
+        self.world_size = world_size
+        self.autocast_dtype = autocast_dtype
+
+    def set_lr(self, lr):
+        self.lr = lr
+
+    def _adam_step(self):
+        """torch.optim.Adam's single-tensor update (no amsgrad, no weight decay) on the flat buffers."""
+        self.step_count += 1
+        b1, b2 = self.betas
+        g, p = self.bucket.grad, self.bucket.data
+        self.exp_avg.lerp_(g, 1 - b1)
+        self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1 = 1 - b1 ** self.step_count
+        bc2 = 1 - b2 ** self.step_count
+        denom = (self.exp_avg_sq.sqrt() / math.sqrt(bc2)).add_(self.eps)
+        p.addcdiv_(self.exp_avg, denom, value=-self.lr / bc1)
+
+    def update_minibatch(self, obs, merged, act, old_logp, adv, ret, clip_eps=CLIP_EPS, ent_coef=ENT_COEF_START):
+        self.bucket.grad.zero_()
+        dev_type = self.bucket.data.device.type
+        if self.autocast_dtype is not None:
+            with torch.autocast(device_type=dev_type, dtype=self.autocast_dtype):
+                loss, stats = ppo_loss(self.model, obs, merged, act, old_logp, adv, ret, clip_eps, ent_coef)
+        else:
+            loss, stats = ppo_loss(self.model, obs, merged, act, old_logp, adv, ret, clip_eps, ent_coef)
+        loss.backward()
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.bucket.grad, op=dist.ReduceOp.SUM, group=self.pg)
+            self.bucket.grad.div_(self.world_size)
+        # clip_grad_norm_(parameters, 0.5): 2-norm of the per-tensor 2-norms (the reference's summation order; a single
+        # fp32 reduction over the 2.6 M-element flat buffer is measurably less accurate on the CPU), then scale by
+        # max_norm / (norm + 1e-6) if that is < 1
+        gn = torch.linalg.vector_norm(torch.stack(torch._foreach_norm([p.grad for p in self.bucket.params])))
+        self.bucket.grad.mul_(torch.clamp(MAX_GRAD_NORM / (gn + 1e-6), max=1.0))
+        self._adam_step()
+        self.ema.mul_(EMA_DECAY).add_(self.bucket.data, alpha=1 - EMA_DECAY)
+        stats["grad_norm"] = gn.detach()
+        return stats
+
+    def ema_state_dict(self):
+        """state_dict of the EMA weights with the reference's parameter names (what :647-651 saves)."""
+        sd = {k: v.clone() for k, v in self.model.state_dict().items()}
+        off = 0
+        names = [n for n, p in self.model.named_parameters() if p.requires_grad]
+        for n, p in zip(names, self.bucket.params):
+            k = p.numel()
+            sd[n] = self.ema[off:off + k].view_as(p).clone()
+            off += k
+        return sd
+
+
+def schedule(update, total_updates):
+    """Linear lr / entropy-coefficient anneal and the clip switch (pacman_mappo_resnet.py:386-391)."""
+    progress = update / total_updates
+    lr = LR_START - (LR_START - LR_END) * progress
+    ent = ENT_COEF_START - (ENT_COEF_START - ENT_COEF_END) * progress
+    clip = 0.1 if update > 800 else CLIP_EPS
+    return lr, ent, clip
