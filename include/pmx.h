@@ -43,6 +43,13 @@ enum {
 
 enum { PMX_OBS_F32 = 0, PMX_OBS_BF16 = 1, PMX_OBS_U8 = 2 };
 
+/* Action code for an in-kernel randomTeam opponent (agents/randomTeam.py:90-100: random.choice(legal actions)):
+ * the env itself picks uniformly among the agent's legal actions ON THE MID-TICK STATE, in the reference's list order
+ * N,S,E,W,Stop, with a counter-based generator keyed by (config seed, env index, tick counter, agent).  The draw is
+ * distribution-equivalent to the reference's (which uses Python's global Mersenne Twister) and is reproduced exactly
+ * by the test oracle. */
+#define PMX_ACTION_RANDOM_LEGAL (-2)
+
 typedef struct pmx_env pmx_env;
 
 /* What gymPacMan_parallel_env.__init__ takes (gymPacMan.py:15) plus the batch size.  The .lay text is parsed
@@ -63,6 +70,7 @@ typedef struct {
     int32_t obs_dtype;           /* PMX_OBS_*: element type of the observation planes (reference: float32) */
     int32_t obs_agents;          /* bit i set = emit agent i's observation; 0 means all four (0xF) */
     int32_t device;              /* HIP device ordinal */
+    uint32_t seed;               /* key of the PMX_ACTION_RANDOM_LEGAL generator */
 } pmx_config;
 
 /* Outputs of one tick = what gymPacMan.step returns (gymPacMan.py:191-193), batched.  Any pointer may be
@@ -77,6 +85,10 @@ typedef struct {
     int32_t *score_change_dev;   /* [n_envs] info['score_change'] */
     int32_t *score_dev;          /* [n_envs] game.state.data.score after the tick, BEFORE any auto-reset
                                     (pacman_mappo_resnet.py:529 reads it at a done) */
+    uint32_t *agent_dev;         /* [n_envs][4] x | y << 8 | numCarrying << 16 of each agent right after its OWN sub-step,
+                                    before any auto-reset: the content of observation plane 1 in compact form, which
+                                    is all that get_agent_state / compute_heuristic_shaping read
+                                    (pacman_mappo_resnet.py:241-264) */
 } pmx_step_out;
 
 /* Dynamic part of one game = the fields of capture.GameState / game.AgentState that the path reads
@@ -92,6 +104,7 @@ typedef struct {
     uint32_t caps[PMX_MAX_DIM];
     int32_t score;
     int32_t steps;               /* gymPacMan_parallel_env.steps */
+    uint32_t ticks;              /* ticks since pmx_create (never reset): counter of the random-legal generator */
 } pmx_state;
 
 int pmx_version(void);

@@ -24,7 +24,7 @@ def build(force=False):
 class PState(C.Structure):
     _fields_ = [("pos", (C.c_int8 * 2) * 4), ("dir", C.c_int8 * 4), ("pac", C.c_uint8 * 4), ("scared", C.c_uint8 * 4),
                 ("carry", C.c_uint8 * 4), ("ret", C.c_uint8 * 4), ("food", C.c_uint32 * MAXD), ("caps", C.c_uint32 * MAXD),
-                ("score", C.c_int32), ("steps", C.c_int32)]
+                ("score", C.c_int32), ("steps", C.c_int32), ("ticks", C.c_uint32)]
 
 
 class SubOut(C.Structure):
@@ -32,7 +32,7 @@ class SubOut(C.Structure):
 
 
 class Cfg(C.Structure):
-    _fields_ = [("length", C.c_int), ("legal_reward", C.c_int), ("defence_reward", C.c_int)]
+    _fields_ = [("length", C.c_int), ("legal_reward", C.c_int), ("defence_reward", C.c_int), ("seed", C.c_uint32)]
 
 
 _lib = None
@@ -93,7 +93,7 @@ class Env:
     def __init__(self, rows, length=299, legal_reward=True, defence_reward=True):
         self.L = Layout(rows)
         self.lib = lib()
-        self.cfg = Cfg(int(length), int(bool(legal_reward)), int(bool(defence_reward)))
+        self.cfg = Cfg(int(length), int(bool(legal_reward)), int(bool(defence_reward)), 0)
         self.S = C.create_string_buffer(self.lib.orc_sizeof_state())
         self.reset()
 
@@ -159,11 +159,11 @@ class Env:
 class BatchEnv:
     """N oracle envs of one layout stepped in a C loop (differential tests at scale, CPU baseline)."""
 
-    def __init__(self, rows, n, length=299, legal_reward=True, defence_reward=True, auto_reset=True):
+    def __init__(self, rows, n, length=299, legal_reward=True, defence_reward=True, auto_reset=True, seed=0):
         self.L = Layout(rows)
         self.lib = lib()
         self.n = n
-        self.cfg = Cfg(int(length), int(bool(legal_reward)), int(bool(defence_reward)))
+        self.cfg = Cfg(int(length), int(bool(legal_reward)), int(bool(defence_reward)), int(seed))
         self.ssz = self.lib.orc_sizeof_state()
         self.S = C.create_string_buffer(self.ssz * n)
         self.auto_reset = int(auto_reset)
@@ -173,13 +173,16 @@ class BatchEnv:
         self.done = np.zeros(n, np.uint8)
         self.legal = np.zeros((n, 4), np.uint8)
         self.score_change = np.zeros(n, np.int32)
+        self.score = np.zeros(n, np.int32)
+        self.agent = np.zeros((n, 4), np.uint32)
 
     def tick(self, actions, obs=None):
         a = np.ascontiguousarray(actions, np.int8)
         assert a.shape == (self.n, 4)
         self.lib.orc_tick_batch(self.L.buf, C.byref(self.cfg), self.S, self.n, a.ctypes,
                                 obs.ctypes if obs is not None else None, self.reward.ctypes, self.done.ctypes,
-                                self.legal.ctypes, self.score_change.ctypes, self.auto_reset)
+                                self.legal.ctypes, self.score_change.ctypes, self.auto_reset, self.score.ctypes,
+                                self.agent.ctypes)
 
     def get_state(self, e):
         p = PState()

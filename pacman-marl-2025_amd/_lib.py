@@ -8,6 +8,7 @@ from . import build as _build
 
 PMX_MAX_DIM = 32
 OBS_F32, OBS_BF16, OBS_U8 = 0, 1, 2
+ACTION_RANDOM_LEGAL = -2
 
 
 class PmxError(RuntimeError):
@@ -20,18 +21,19 @@ class Config(C.Structure):
                 ("cap_rows", C.POINTER(C.c_uint32)), ("starts", C.POINTER(C.c_int8)),
                 ("n_envs", C.c_int32), ("length", C.c_int32), ("legal_reward", C.c_int32),
                 ("defence_reward", C.c_int32), ("auto_reset", C.c_int32), ("obs_dtype", C.c_int32),
-                ("obs_agents", C.c_int32), ("device", C.c_int32)]
+                ("obs_agents", C.c_int32), ("device", C.c_int32), ("seed", C.c_uint32)]
 
 
 class StepOut(C.Structure):
     _fields_ = [("obs_dev", C.c_void_p), ("reward_dev", C.c_void_p), ("done_dev", C.c_void_p),
-                ("legal_dev", C.c_void_p), ("score_change_dev", C.c_void_p), ("score_dev", C.c_void_p)]
+                ("legal_dev", C.c_void_p), ("score_change_dev", C.c_void_p), ("score_dev", C.c_void_p),
+                ("agent_dev", C.c_void_p)]
 
 
 class State(C.Structure):
     _fields_ = [("pos", (C.c_int8 * 2) * 4), ("dir", C.c_int8 * 4), ("pac", C.c_uint8 * 4), ("scared", C.c_uint8 * 4),
                 ("carry", C.c_uint16 * 4), ("ret", C.c_uint16 * 4), ("food", C.c_uint32 * PMX_MAX_DIM),
-                ("caps", C.c_uint32 * PMX_MAX_DIM), ("score", C.c_int32), ("steps", C.c_int32)]
+                ("caps", C.c_uint32 * PMX_MAX_DIM), ("score", C.c_int32), ("steps", C.c_int32), ("ticks", C.c_uint32)]
 
 
 # every symbol include/pmx.h declares: (name, restype, argtypes)

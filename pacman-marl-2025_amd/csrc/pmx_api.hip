@@ -102,7 +102,9 @@ void fill_tick_params(pmx_env *env, PmxTickParams &p, const int8_t *actions, con
         p.legal = out->legal_dev;
         p.score_change = out->score_change_dev;
         p.score = out->score_dev;
+        p.agent_out = out->agent_dev;
     }
+    p.seed = env->cfg.seed;
 }
 
 // when profiling, returns the pair of events to record around the next launch of that kernel (or nullptr)
@@ -234,6 +236,7 @@ int pmx_create(const pmx_config *cfg, pmx_env **out)
     if (e == hipSuccess) e = hipMalloc((void **)&env->dump_dev, dump.size());
     if (e == hipSuccess) e = hipMalloc((void **)&env->state_dev, PMX_STATE_WORDS(H) * N * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&env->snap_dev, 3 * (size_t)PMX_SNAP_WORDS(H) * N * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(env->state_dev, 0, PMX_STATE_WORDS(H) * N * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpy(env->lay_dev, &L, sizeof(L), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(env->dump_dev, dump.data(), dump.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -303,7 +306,7 @@ int pmx_step_agent(pmx_env *env, int agent, const int8_t *actions_dev, const pmx
     if (agent != env->open_agent)
         return fail(PMX_ERR_INVALID, "pmx_step_agent: expected agent %d, got %d (sub-steps run 0,1,2,3)", env->open_agent, agent);
     PmxTickParams p;
-    fill_tick_params(env, p, actions_dev, agent == 3 ? out : nullptr);
+    fill_tick_params(env, p, actions_dev, out);   // the kernel writes the tick-level outputs only when agent == 3
     HIP_TRY(pmx_launch_rule_agent(&p, env->lay.H, agent, as_stream(stream)));
     env->open_agent = (agent + 1) & 3;
     if (out && out->obs_dev) return launch_expand(env, out->obs_dev, false, agent, as_stream(stream));
@@ -400,6 +403,7 @@ int pmx_get_state(pmx_env *env, int32_t first, int32_t count, pmx_state *states,
         }
         s.score = (int32_t)word(PMX_W_SCORE(H));
         s.steps = (int32_t)word(PMX_W_STEPS(H));
+        s.ticks = word(PMX_W_TICKS(H));
     }
     return PMX_OK;
 }
@@ -439,6 +443,7 @@ int pmx_set_state(pmx_env *env, int32_t first, int32_t count, const pmx_state *s
         word(PMX_W_CAPS(H, 1)) = slots[2] | ((uint32_t)slots[3] << 16);
         word(PMX_W_SCORE(H)) = (uint32_t)s.score;
         word(PMX_W_STEPS(H)) = (uint32_t)s.steps;
+        word(PMX_W_TICKS(H)) = s.ticks;
     }
     HIP_TRY(hipMemcpy2DAsync(env->state_dev + first, (size_t)N * 4, buf.data(), (size_t)count * 4, (size_t)count * 4, words,
                              hipMemcpyHostToDevice, as_stream(stream)));

@@ -19,7 +19,8 @@
 //   H + 8, H + 9  capsule list: four 16-bit slots (x | y << 8), 0xFFFF = empty
 //   H + 10        score (int32)
 //   H + 11        steps (int32)
-//   H + 12 ...    accumulators of an open tick, used only by pmx_step_agent:
+//   H + 12        ticks since creation (never reset): counter of the PMX_ACTION_RANDOM_LEGAL generator
+//   H + 13 ...    accumulators of an open tick, used only by pmx_step_agent:
 //                 red reward (2 words, f64), blue reward (2 words), red score change, blue score change, total
 // A "snapshot" is the first H + 10 words of this layout; the observation encoder reads snapshots.
 // ---------------------------------------------------------------------------------------------
@@ -28,9 +29,10 @@
 #define PMX_W_CAPS(H, j) ((H) + 8 + (j))
 #define PMX_W_SCORE(H) ((H) + 10)
 #define PMX_W_STEPS(H) ((H) + 11)
-#define PMX_W_ACC(H) ((H) + 12)
+#define PMX_W_TICKS(H) ((H) + 12)
+#define PMX_W_ACC(H) ((H) + 13)
 #define PMX_SNAP_WORDS(H) ((H) + 10)
-#define PMX_STATE_WORDS(H) ((H) + 19)
+#define PMX_STATE_WORDS(H) ((H) + 20)
 
 struct PmxLayoutDev {
     int32_t W, H, half;          // half = int(W / 2): the food split (capture.py:333)
@@ -56,6 +58,8 @@ struct PmxTickParams {
     uint8_t *legal;
     int32_t *score_change;
     int32_t *score;
+    uint32_t *agent_out;         // [N][4] x | y<<8 | carry<<16 right after the agent's own sub-step
+    uint32_t seed;
     const uint8_t *reset_mask;   // reset kernel only: NULL = every env
     int32_t no_reset;            // reset kernel only: 1 = touch no env (legal masks of the current state only)
 };

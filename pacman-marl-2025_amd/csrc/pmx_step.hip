@@ -18,6 +18,8 @@ struct Env {
     int x[4], y[4], dir[4], pac[4], scared[4], carry[4], ret[4];
     uint32_t capw[2];
     int score, steps;
+    uint32_t ticks;        // never reset
+    uint32_t self_after[4];  // x | y<<8 | carry<<16 of agent i right after its own sub-step
 };
 
 struct Acc {
@@ -32,6 +34,7 @@ struct Ctx {
     const int8_t *dump;
     int W, H, half, n_dump;
     int legal_reward, defence_reward;
+    uint32_t rng_key;     // seed ^ env * 0x9E3779B1 (the per-env part of the random-legal key)
 };
 
 __device__ __forceinline__ uint32_t pack_a(const Env &e, int i)
@@ -134,6 +137,24 @@ __device__ __forceinline__ void consume(Env &e, const Ctx &c, int px, int py, in
 
 // capture.py:107-123 generateSuccessor for mover I, in place.  Returns scoreChange; d_red/d_blue receive the net
 // change of the food counts on the red / blue side (what gymPacMan.get_reward compares, gymPacMan.py:234-247).
+// PMX_ACTION_RANDOM_LEGAL: uniform choice among the legal actions in the reference's list order N,S,E,W,Stop
+// (agents/randomTeam.py:100 random.choice(actions)); lowbias32 hash of (seed, env, tick, agent) as the generator.
+__device__ __forceinline__ int random_legal(int legal, uint32_t key, uint32_t ticks, int agent)
+{
+    uint32_t x = key ^ (ticks * 0x85EBCA77u) ^ ((uint32_t)agent * 0xC2B2AE3Du);
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    const uint32_t n = (uint32_t)__popc(legal);
+    int k = (int)(((uint64_t)x * n) >> 32);
+    int pick = 4;
+    const int order[5] = { 0, 2, 1, 3, 4 };
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int a = order[j];
+        if ((legal >> a) & 1) { if (k == 0) pick = a; --k; }
+    }
+    return pick;
+}
+
 template <int I>
 __device__ __forceinline__ int substep(Env &e, const Ctx &c, int action, bool &req_legal, int &d_red, int &d_blue)
 {
@@ -141,6 +162,7 @@ __device__ __forceinline__ int substep(Env &e, const Ctx &c, int action, bool &r
     constexpr int O1 = RED ? 1 : 0, O2 = O1 + 2;
     // ---- applyAction capture.py:468-517
     const int legal = legal_mask(c.wl, e.x[I], e.y[I]);
+    if (action == -2) action = random_legal(legal, c.rng_key, e.ticks, I);
     req_legal = (action >= 0) && (action <= 4) && ((legal >> (action & 7)) & 1);
     if (!req_legal) action = 4;                                           // :473-474
     const int dx = (action == 1) - (action == 3), dy = (action == 0) - (action == 2);
@@ -208,6 +230,7 @@ __device__ __forceinline__ void tick_substep(Env &e, Acc &a, const Ctx &c, int a
     if (c.legal_reward && req_legal) r += 0.01;                           // :254-257
     if (RED) { a.red_r = r; a.red_sc += sc; } else { a.blue_r = r; a.blue_sc -= sc; }
     a.sc_total += sc;                                                     // :153-162
+    e.self_after[I] = (uint32_t)e.x[I] | ((uint32_t)e.y[I] << 8) | ((uint32_t)e.carry[I] << 16);
 }
 
 __device__ __forceinline__ void load_env(Env &e, const Ctx &c, const uint32_t *st, int N, int env)
@@ -222,6 +245,7 @@ __device__ __forceinline__ void load_env(Env &e, const Ctx &c, const uint32_t *s
     e.capw[1] = st[(size_t)PMX_W_CAPS(c.H, 1) * N + env];
     e.score = (int)st[(size_t)PMX_W_SCORE(c.H) * N + env];
     e.steps = (int)st[(size_t)PMX_W_STEPS(c.H) * N + env];
+    e.ticks = st[(size_t)PMX_W_TICKS(c.H) * N + env];
 }
 
 // first PMX_SNAP_WORDS words (food, agents, capsules)
@@ -242,6 +266,7 @@ __device__ __forceinline__ void store_env(const Env &e, const Ctx &c, uint32_t *
     store_snapshot(e, c, st, N, env);
     st[(size_t)PMX_W_SCORE(c.H) * N + env] = (uint32_t)e.score;
     st[(size_t)PMX_W_STEPS(c.H) * N + env] = (uint32_t)e.steps;
+    st[(size_t)PMX_W_TICKS(c.H) * N + env] = e.ticks;
 }
 
 // game.py:490-508 GameStateData.initialize + gymPacMan.py:94 steps = 0
@@ -258,7 +283,7 @@ __device__ __forceinline__ void init_env(Env &e, const Ctx &c)
 }
 
 // gymPacMan.py:171-193: everything after the four sub-steps.
-__device__ __forceinline__ void tick_finish(Env &e, Acc &a, const Ctx &c, const PmxTickParams &p, int env)
+__device__ __forceinline__ void tick_finish(Env &e, Acc &a, const Ctx &c, const PmxTickParams &p, int env, bool fused)
 {
     double blue_r = a.blue_r + (double)(a.blue_sc > 0 ? a.blue_sc : 0);   // :171-172
     double red_r = a.red_r + (double)(a.red_sc > 0 ? a.red_sc : 0);
@@ -276,6 +301,11 @@ __device__ __forceinline__ void tick_finish(Env &e, Acc &a, const Ctx &c, const 
         else if (fs > 0) red_r += 20.0 + (1.0 / 5) * (double)fs;
     }
     e.steps += 1;                                                         // :189
+    e.ticks += 1;
+    if (p.agent_out && fused) {
+        uint4 v = make_uint4(e.self_after[0], e.self_after[1], e.self_after[2], e.self_after[3]);
+        reinterpret_cast<uint4 *>(p.agent_out)[env] = v;
+    }
     if (p.reward) { p.reward[2 * (size_t)env] = red_r; p.reward[2 * (size_t)env + 1] = blue_r; }
     if (p.done) p.done[env] = (uint8_t)done;
     if (p.score_change) p.score_change[env] = a.sc_total;
@@ -303,6 +333,7 @@ __device__ __forceinline__ Ctx make_ctx(const PmxTickParams &p, uint32_t *lds)
     c.legal_reward = p.legal_reward; c.defence_reward = p.defence_reward;
     c.wl = lds;
     c.fd = lds + 32 + threadIdx.x;
+    c.rng_key = p.seed ^ ((uint32_t)(blockIdx.x * PMX_RULE_BLOCK + threadIdx.x) * 0x9E3779B1u);
     if (threadIdx.x < 32) lds[threadIdx.x] = threadIdx.x < (unsigned)c.H ? p.lay->walls[threadIdx.x] : 0xFFFFFFFFu;
     __syncthreads();
     return c;
@@ -329,7 +360,7 @@ extern "C" __global__ __launch_bounds__(PMX_RULE_BLOCK) void pmx_rule_kernel(Pmx
     tick_substep<2>(e, a, c, (int)(int8_t)((av >> 16) & 0xFF));
     store_snapshot(e, c, p.snap + 2 * snap_sz, p.N, env);
     tick_substep<3>(e, a, c, (int)(int8_t)((av >> 24) & 0xFF));
-    tick_finish(e, a, c, p, env);
+    tick_finish(e, a, c, p, env, true);
     store_env(e, c, p.state, p.N, env);
 }
 
@@ -349,9 +380,13 @@ __device__ __forceinline__ void rule_agent_body(const PmxTickParams &p, uint32_t
         a.blue_r = __hiloint2double((int)acc[(size_t)3 * p.N], (int)acc[(size_t)2 * p.N]);
         a.red_sc = (int)acc[(size_t)4 * p.N]; a.blue_sc = (int)acc[(size_t)5 * p.N]; a.sc_total = (int)acc[(size_t)6 * p.N];
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)   // sub-steps not yet taken report the current state
+        e.self_after[i] = (uint32_t)e.x[i] | ((uint32_t)e.y[i] << 8) | ((uint32_t)e.carry[i] << 16);
     tick_substep<I>(e, a, c, (int)p.actions[env]);
+    if (p.agent_out) p.agent_out[4 * (size_t)env + I] = e.self_after[I];
     if (I == 3) {
-        tick_finish(e, a, c, p, env);
+        tick_finish(e, a, c, p, env, false);
     } else {
         acc[0] = (uint32_t)__double2loint(a.red_r); acc[(size_t)1 * p.N] = (uint32_t)__double2hiint(a.red_r);
         acc[(size_t)2 * p.N] = (uint32_t)__double2loint(a.blue_r); acc[(size_t)3 * p.N] = (uint32_t)__double2hiint(a.blue_r);
@@ -381,6 +416,7 @@ extern "C" __global__ __launch_bounds__(PMX_RULE_BLOCK) void pmx_reset_kernel(Pm
     Env e;
     if (!p.no_reset && (!p.reset_mask || p.reset_mask[env])) {
         init_env(e, c);
+        e.ticks = p.state[(size_t)PMX_W_TICKS(c.H) * p.N + env];
         store_env(e, c, p.state, p.N, env);
         for (int k = 0; k < 7; ++k) p.state[(size_t)(PMX_W_ACC(c.H) + k) * p.N + env] = 0;
     } else if (p.legal) {

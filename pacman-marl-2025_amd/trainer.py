@@ -1,0 +1,246 @@
+"""Vectorised MAPPO training loop on the GPU env (the rollout / GAE / PPO-update part of pacman_mappo_resnet.train()).
+
+Per update (pacman_mappo_resnet.py:385-600), with N envs in lock-step instead of one:
+  rollout  T ticks: canonicalise (red learners) and merge the two learner observations, sample both learners'
+           actions from the actor and one value from the critic, step the env, add the heuristic shaping
+           (:241-264, :513-522), store everything in DEVICE-resident buffers (:449-455 kept them on the CPU)
+  GAE      pmx_gae over the [T][2N] series (:548-553)
+  update   UPDATE_EPOCHS x minibatches of the flattened [T*N*2] samples through PPOLearner (:556-595)
+Opponents: the in-kernel randomTeam bot (PMX_ACTION_RANDOM_LEGAL), the current network, or a frozen EMA snapshot from
+the opponent pool (:396-438; the scripted bot zoo of the reference's curriculum is out of scope).
+"""
+import copy
+import ctypes as C
+from collections import deque
+
+import numpy as np
+import torch
+
+from . import _lib, mappo
+from .vec_env import PmxVecEnv
+
+UPDATE_EPOCHS = 3                 # pacman_mappo_resnet.py:24
+OPPONENT_POOL_SIZE = 80           # :32
+OPPONENT_UPDATE_FREQ = 15         # :33
+
+
+def shaping_from_agent_words(prev, cur):
+    """compute_heuristic_shaping (pacman_mappo_resnet.py:251-264) from the compact self plane.
+    prev/cur: int32 [...]: x | y << 8 | carry << 16 of the same agent in two consecutive observations.  float64."""
+    px, py, pc = prev & 0xFF, (prev >> 8) & 0xFF, (prev >> 16) & 0xFFFF
+    cx, cy = cur & 0xFF, (cur >> 8) & 0xFF
+    moved = (px - cx).abs() + (py - cy).abs()
+    living = -0.15
+    died = (living - 0.4) - (0.15 * pc.to(torch.float64))
+    out = torch.full(prev.shape, living, dtype=torch.float64, device=prev.device)
+    out = torch.where(moved == 0, torch.full_like(out, living - 0.05), out)     # dist_moved < 0.1
+    out = torch.where(moved > 1, died, out)                                     # dist_moved > 1.5
+    return out
+
+
+def merge_obs(a, b):
+    """merge_obs_for_critic (pacman_mappo_resnet.py:267-274) on batches [N,8,H,W]."""
+    m = a.clone()
+    m[:, 1] = torch.maximum(torch.maximum(a[:, 1], b[:, 1]), torch.zeros_like(a[:, 1]))
+    m[:, 4] = 0
+    return m
+
+
+def canonicalize_obs(o):
+    """canonicalize_obs for a red learner (pacman_mappo_resnet.py:215-229): flip x, swap planes 2<->3, 6<->7."""
+    return torch.flip(o, dims=[-1])[..., [0, 1, 3, 2, 4, 5, 7, 6], :, :]
+
+
+class VecMAPPOTrainer:
+    def __init__(self, layout, n_envs, horizon=32, minibatch=512, epochs=UPDATE_EPOCHS, obs_dtype="bfloat16",
+                 device="cuda:0", seed=0, rank=0, world_size=1, process_group=None, total_updates=2000, length=300,
+                 use_autocast=True, opponent="random"):
+        self.device = torch.device(device)
+        self.rank, self.world_size = rank, world_size
+        self.env = PmxVecEnv(layout, n_envs, length=length, reward_forLegalAction=True, defenceReward=True,
+                             auto_reset=True, obs_dtype=obs_dtype, device=self.device, seed=seed * 1000003 + rank)
+        self.N, self.T = n_envs, horizon
+        self.minibatch, self.epochs = minibatch, epochs
+        self.total_updates = total_updates
+        H, W = self.env.layout.height, self.env.layout.width
+        self.obs_shape = (8, H, W)
+        torch.manual_seed(seed)                                   # identical initial weights on every rank
+        self.model = mappo.MAPPOAgent(self.obs_shape, 5, 2).to(self.device)
+        self.autocast_dtype = torch.bfloat16 if use_autocast else None
+        self.learner = mappo.PPOLearner(self.model, process_group=process_group, world_size=world_size,
+                                        autocast_dtype=self.autocast_dtype)
+        if world_size > 1:
+            import torch.distributed as dist
+            dist.broadcast(self.learner.bucket.data, src=0, group=process_group)
+            self.learner.ema.copy_(self.learner.bucket.data)
+        self.opponent_model = mappo.MAPPOAgent(self.obs_shape, 5, 2).to(self.device)
+        self.opponent_model.load_state_dict(self.model.state_dict())
+        self.opponent_model.eval()
+        self.opponent_pool = deque(maxlen=OPPONENT_POOL_SIZE)
+        self.opponent_pool.append(self.learner.ema_state_dict())
+        self.opponent_mode = opponent                              # "random" | "self" | "pool" | "curriculum"
+        self.gen = torch.Generator(device=self.device).manual_seed(seed * 7919 + rank)
+        self.np_rng = np.random.RandomState(seed * 31 + rank)
+        dt, dev, N, T = self.env.obs_torch_dtype, self.device, n_envs, horizon
+        self.obs_buf = torch.zeros((T, N, 2) + self.obs_shape, dtype=dt, device=dev)
+        self.merged_buf = torch.zeros((T, N) + self.obs_shape, dtype=dt, device=dev)
+        self.act_buf = torch.zeros((T, N, 2), dtype=torch.int64, device=dev)
+        self.logp_buf = torch.zeros((T, N, 2), dtype=torch.float32, device=dev)
+        self.rew_buf = torch.zeros((T, N, 2), dtype=torch.float32, device=dev)
+        self.done_buf = torch.zeros((T, N, 2), dtype=torch.float32, device=dev)
+        self.val_buf = torch.zeros((T, N, 2), dtype=torch.float32, device=dev)
+        self.adv_buf = torch.zeros((T, N, 2), dtype=torch.float32, device=dev)
+        self.ret_buf = torch.zeros((T, N, 2), dtype=torch.float32, device=dev)
+        starts = self.env.layout.starts.astype(np.int64)
+        self.start_words = torch.tensor([int(starts[i, 0]) | (int(starts[i, 1]) << 8) for i in range(4)],
+                                        dtype=torch.int32, device=dev)
+        self.cur_obs, _ = self.env.reset()
+        self.prev_agent = self.start_words[None].expand(N, 4).clone()
+        self.update_idx = 0
+        self.stats = {}
+
+    # ---------------------------------------------------------------------------------------------------------
+    def _net_in(self, x):
+        """Observation tensors are small integers: hand the network bf16 under autocast, fp32 otherwise."""
+        return x.to(torch.bfloat16) if self.autocast_dtype is not None else x.float()
+
+    def _forward_policy(self, model, obs2, merged, want_value):
+        ctx = torch.autocast(device_type=self.device.type, dtype=self.autocast_dtype) if self.autocast_dtype else _NullCtx()
+        with torch.no_grad(), ctx:
+            a, lp = model.act(self._net_in(obs2.reshape((-1,) + self.obs_shape)), generator=self.gen)
+            v = model.value(self._net_in(merged)).float() if want_value else None
+        return a.view(-1, 2), lp.view(-1, 2), v
+
+    def _pick_opponent(self):
+        """The self-play part of the curriculum (pacman_mappo_resnet.py:396-438) with the opponents this build has."""
+        mode = self.opponent_mode
+        if mode == "curriculum":
+            if self.update_idx <= 200:
+                mode = "random"
+            else:
+                r = self.np_rng.rand()
+                mode = "self" if r < 0.40 else ("pool" if r < 0.60 else "random")
+        play_as_red = False
+        if mode == "self":
+            play_as_red = bool(self.np_rng.rand() > 0.5)
+            self.opponent_model.load_state_dict(self.model.state_dict())
+        elif mode == "pool":
+            play_as_red = bool(self.np_rng.rand() > 0.5)
+            self.opponent_model.load_state_dict(self.opponent_pool[self.np_rng.randint(len(self.opponent_pool))])
+        return mode, play_as_red
+
+    def rollout(self):
+        env, N, T = self.env, self.N, self.T
+        mode, red = self._pick_opponent()
+        learner_ids = [0, 2] if red else [1, 3]
+        opp_ids = [1, 3] if red else [0, 2]
+        team = 0 if red else 1
+        ep_ret = torch.zeros((), dtype=torch.float64, device=self.device)
+        n_done = torch.zeros((), dtype=torch.int64, device=self.device)
+        n_win = torch.zeros((), dtype=torch.int64, device=self.device)
+        for t in range(T):
+            raw = self.cur_obs                                       # [N,4,8,H,W], the env's own output buffer
+            lo = raw[:, learner_ids]
+            if red:
+                lo = canonicalize_obs(lo)
+            self.obs_buf[t].copy_(lo)
+            merged = merge_obs(self.obs_buf[t, :, 0], self.obs_buf[t, :, 1])
+            self.merged_buf[t].copy_(merged)
+            a, lp, v = self._forward_policy(self.model, self.obs_buf[t], merged, True)
+            self.act_buf[t].copy_(a)
+            self.logp_buf[t].copy_(lp)
+            self.val_buf[t].copy_(v[:, None].expand(N, 2))
+            acts = torch.full((N, 4), _lib.ACTION_RANDOM_LEGAL, dtype=torch.int8, device=self.device)
+            acts[:, learner_ids] = mappo.canonicalize_action(a, red).to(torch.int8)
+            if mode in ("self", "pool"):
+                oo = raw[:, opp_ids]
+                if not red:
+                    oo = canonicalize_obs(oo)                        # the opponent is red when the learner is blue
+                oa, _, _ = self._forward_policy(self.opponent_model, oo, None, False)
+                acts[:, opp_ids] = mappo.canonicalize_action(oa, not red).to(torch.int8)
+            obs, rew, done, info = env.step(acts)
+            cur_agent = info["agent"]
+            shp = shaping_from_agent_words(self.prev_agent[:, learner_ids], cur_agent[:, learner_ids])   # [N,2] f64
+            team_reward = rew[:, team] + rew[:, team]                # sum over the two learners' (identical) rewards
+            self.rew_buf[t].copy_((team_reward[:, None] + mappo.SHAPING_SCALE * shp).to(torch.float32))
+            d = done.to(torch.bool)
+            self.done_buf[t].copy_(done.to(torch.float32)[:, None].expand(N, 2))
+            self.prev_agent = torch.where(d[:, None], self.start_words[None].expand(N, 4), cur_agent)
+            ep_ret += team_reward.sum()
+            n_done += d.sum()
+            sc = info["score"]
+            n_win += (d & ((sc > 0) if red else (sc < 0))).sum()
+            self.cur_obs = obs
+        # bootstrap value of the state after the last tick (:541-546)
+        lo = self.cur_obs[:, learner_ids]
+        if red:
+            lo = canonicalize_obs(lo)
+        last_merged = merge_obs(lo[:, 0].contiguous(), lo[:, 1].contiguous())
+        ctx = torch.autocast(device_type=self.device.type, dtype=self.autocast_dtype) if self.autocast_dtype else _NullCtx()
+        with torch.no_grad(), ctx:
+            self.last_value = self.model.value(self._net_in(last_merged)).float()
+        self.stats.update(opponent=mode, play_as_red=red, rollout_reward=ep_ret, episodes=n_done, wins=n_win)
+
+    def compute_gae(self):
+        T, n = self.T, self.N * 2
+        last = self.last_value[:, None].expand(self.N, 2).contiguous()
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self.env.lib.pmx_gae(self.rew_buf.data_ptr(), self.val_buf.data_ptr(), self.done_buf.data_ptr(),
+                                        last.data_ptr(), T, n, mappo.GAMMA, mappo.GAE_LAMBDA, self.adv_buf.data_ptr(),
+                                        self.ret_buf.data_ptr(), st), "pmx_gae")
+
+    def update(self):
+        lr, ent_coef, clip_eps = mappo.schedule(self.update_idx, self.total_updates)
+        self.learner.set_lr(lr)
+        S = self.T * self.N * 2
+        obs = self.obs_buf.view((S,) + self.obs_shape)
+        merged = self.merged_buf.view((self.T * self.N,) + self.obs_shape)
+        act, logp = self.act_buf.view(S), self.logp_buf.view(S)
+        adv, ret = self.adv_buf.view(S), self.ret_buf.view(S)
+        agg = None
+        steps = 0
+        for _ in range(self.epochs):
+            perm = torch.randperm(S, device=self.device, generator=self.gen)
+            for s0 in range(0, S, self.minibatch):
+                mb = perm[s0:s0 + self.minibatch]
+                st = self.learner.update_minibatch(self._net_in(obs[mb]), self._net_in(merged[mb // 2]), act[mb], logp[mb],
+                                                   adv[mb], ret[mb], clip_eps, ent_coef)
+                steps += 1
+                agg = {k: v.clone() for k, v in st.items()} if agg is None else {k: agg[k] + st[k] for k in agg}
+        self.stats.update({k: v / steps for k, v in agg.items()})
+        self.stats.update(lr=lr, ent_coef=ent_coef, clip_eps=clip_eps, optimizer_steps=steps)
+        if self.update_idx % OPPONENT_UPDATE_FREQ == 0:
+            self.opponent_pool.append(self.learner.ema_state_dict())
+        self.update_idx += 1
+
+    def train_update(self):
+        self.rollout()
+        self.compute_gae()
+        self.update()
+        return self.stats
+
+    def save_ema(self, path):
+        """The reference's checkpoint: EMA weights only (pacman_mappo_resnet.py:647-651)."""
+        torch.save(self.learner.ema_state_dict(), path)
+
+    def save_full(self, path):
+        """Full resume state, which the reference lacks: weights, EMA, Adam moments, pool, counters."""
+        torch.save({"data": self.learner.bucket.data, "ema": self.learner.ema, "exp_avg": self.learner.exp_avg,
+                    "exp_avg_sq": self.learner.exp_avg_sq, "step": self.learner.step_count, "update": self.update_idx,
+                    "pool": list(self.opponent_pool), "gen": self.gen.get_state(), "np_rng": self.np_rng.get_state()}, path)
+
+    def load_full(self, path):
+        ck = torch.load(path, map_location=self.device, weights_only=False)
+        self.learner.bucket.data.copy_(ck["data"]); self.learner.ema.copy_(ck["ema"])
+        self.learner.exp_avg.copy_(ck["exp_avg"]); self.learner.exp_avg_sq.copy_(ck["exp_avg_sq"])
+        self.learner.step_count, self.update_idx = ck["step"], ck["update"]
+        self.opponent_pool = deque(ck["pool"], maxlen=OPPONENT_POOL_SIZE)
+        self.gen.set_state(ck["gen"].cpu()); self.np_rng.set_state(ck["np_rng"])
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

@@ -24,7 +24,7 @@ def legal_list(mask):
 
 class PmxVecEnv:
     def __init__(self, layout, n_envs, length=299, reward_forLegalAction=True, defenceReward=True, auto_reset=True,
-                 obs_dtype="float32", obs_agents=(0, 1, 2, 3), device="cuda:0"):
+                 obs_dtype="float32", obs_agents=(0, 1, 2, 3), device="cuda:0", seed=0):
         if not torch.cuda.is_available():
             raise _lib.PmxError("PmxVecEnv needs a GPU: the product has no CPU path")
         self.lib = _lib.load()
@@ -54,6 +54,7 @@ class PmxVecEnv:
         cfg.obs_dtype = self.obs_code
         cfg.obs_agents = sum(1 << a for a in self.obs_agents)
         cfg.device = self.device.index or 0
+        cfg.seed = int(seed) & 0xFFFFFFFF
         self.handle = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.pmx_create(C.byref(cfg), C.byref(self.handle)), "pmx_create")
@@ -67,6 +68,7 @@ class PmxVecEnv:
         self.legal = torch.empty((N, 4), dtype=torch.uint8, device=dev)
         self.score_change = torch.empty((N,), dtype=torch.int32, device=dev)
         self.score = torch.empty((N,), dtype=torch.int32, device=dev)
+        self.agent = torch.zeros((N, 4), dtype=torch.int32, device=dev)   # x | y<<8 | carry<<16 after own sub-step
         self._agent_obs = None
 
     # -- plumbing -------------------------------------------------------------------------------------------------
@@ -82,6 +84,7 @@ class PmxVecEnv:
         o.legal_dev = self.legal.data_ptr()
         o.score_change_dev = self.score_change.data_ptr()
         o.score_dev = self.score.data_ptr()
+        o.agent_dev = self.agent.data_ptr()
         return o
 
     def close(self):
@@ -121,7 +124,7 @@ class PmxVecEnv:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.pmx_step(self.handle, a.data_ptr(), C.byref(out), self._stream()), "pmx_step")
         return self.obs, self.reward, self.done, {"legal_actions": self.legal, "score_change": self.score_change,
-                                                   "score": self.score}
+                                                   "score": self.score, "agent": self.agent}
 
     def step_agent(self, agent, actions, want_obs=True):
         """One agent's sub-step (loop body gymPacMan.py:149-169); agent 3 closes the tick.  actions int8 [N].

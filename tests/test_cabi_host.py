@@ -34,8 +34,8 @@ def test_struct_layouts_match_header():
     import pmx
     L = pmx._lib
     # pmx_state: 8+4+4+4+8+8+128+128+4+4
-    assert C.sizeof(L.State) == 300
-    assert C.sizeof(L.StepOut) == 6 * C.sizeof(C.c_void_p)
+    assert C.sizeof(L.State) == 304
+    assert C.sizeof(L.StepOut) == 7 * C.sizeof(C.c_void_p)
     assert L.Config.n_envs.offset == 8 + 4 * C.sizeof(C.c_void_p)
 
 

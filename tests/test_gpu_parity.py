@@ -21,7 +21,7 @@ def _pmx():
 
 def _state_tuple(s, H):
     return (tuple((s.pos[i][0], s.pos[i][1]) for i in range(4)), tuple(s.dir), tuple(s.pac), tuple(s.scared),
-            tuple(s.carry), tuple(s.ret), tuple(s.food[:H]), tuple(s.caps[:H]), s.score, s.steps)
+            tuple(s.carry), tuple(s.ret), tuple(s.food[:H]), tuple(s.caps[:H]), s.score, s.steps, s.ticks)
 
 
 def _ostate_to_pmx(pmx, p, H):
@@ -152,8 +152,8 @@ def test_differential_vs_oracle(layname, fixture, N, T, dtype):
     lay = pmx.Layout.from_text(rows)
     H, W = lay.height, lay.width
     length = 300
-    env = pmx.PmxVecEnv(lay, N, length=length, auto_reset=True, obs_dtype=dtype)
-    orc = O.BatchEnv(rows, N, length=length, auto_reset=True)
+    env = pmx.PmxVecEnv(lay, N, length=length, auto_reset=True, obs_dtype=dtype, seed=77)
+    orc = O.BatchEnv(rows, N, length=length, auto_reset=True, seed=77)
     env.reset()
     _seed_states(pmx, env, orc, fixture, H)
     rng = np.random.RandomState(5)
@@ -168,6 +168,9 @@ def test_differential_vs_oracle(layname, fixture, N, T, dtype):
             ill = pick & (((legal >> np.clip(a, 0, 4)) & 1) == 0)
             a[ill] = rng.randint(0, 5, size=int(ill.sum()))
         a[rng.rand(N, 4) < 0.01] = rng.choice([-1, 5, 7, 127, -128])
+        a[rng.rand(N, 4) < 0.12] = -2          # PMX_ACTION_RANDOM_LEGAL: the in-kernel randomTeam opponent
+        if t % 40 == 7:
+            a[:, 0] = -2; a[:, 2] = -2         # whole red team random, as in the curriculum's first phase
         orc.tick(a, oobs)
         obs, rew, done, info = env.step(torch.tensor(a).cuda())
         torch.cuda.synchronize()
@@ -175,6 +178,8 @@ def test_differential_vs_oracle(layname, fixture, N, T, dtype):
         assert (done.cpu().numpy() == orc.done).all(), f"t={t} done"
         assert (info["legal_actions"].cpu().numpy() == orc.legal).all(), f"t={t} legal"
         assert (info["score_change"].cpu().numpy() == orc.score_change).all(), f"t={t} score_change"
+        assert (info["score"].cpu().numpy() == orc.score).all(), f"t={t} score"
+        assert (info["agent"].cpu().numpy().astype(np.uint32) == orc.agent).all(), f"t={t} agent words"
         o = obs.float().cpu().numpy()
         bad = np.nonzero((o != oobs).reshape(N, -1).any(1))[0]
         assert len(bad) == 0, f"t={t}: obs differ for envs {bad[:10]}"
@@ -208,6 +213,7 @@ def test_step_agent_equals_step():
             assert torch.equal(sub[i], obs[:, i]), (t, i)
         assert torch.equal(b_env.reward, rew) and torch.equal(b_env.done, done)
         assert torch.equal(b_env.legal, info["legal_actions"]) and torch.equal(b_env.score_change, info["score_change"])
+        assert torch.equal(b_env.agent, info["agent"])
     with pytest.raises(pmx.PmxError):
         b_env.step_agent(2, a[:, 2].contiguous())   # sub-steps must come in order 0,1,2,3
     a_env.close(); b_env.close()
