@@ -134,6 +134,12 @@ int pmx_step(pmx_env *env, const int8_t *actions_dev, const pmx_step_out *out, v
  * and auto-reset, if configured, is applied. */
 int pmx_step_agent(pmx_env *env, int agent, const int8_t *actions_dev, const pmx_step_out *out, void *stream);
 
+/* GameState.generateSuccessor (capture.py:107-123) applied in place to every env: agent `agent` takes actions_dev[env]
+ * (int8 [n_envs]).  No reward, no tick bookkeeping, no termination test: this is the query CaptureAgent bots make on
+ * hypothetical states (agents/baselineTeam.py:94-104), normally on a small scratch handle loaded with pmx_set_state.
+ * score_change_dev (may be NULL) receives data.scoreChange of each successor. */
+int pmx_successor(pmx_env *env, int agent, const int8_t *actions_dev, int32_t *score_change_dev, void *stream);
+
 /* Observation planes / legal masks of the CURRENT state for all emitted agents (gymPacMan.get_Observation,
  * gymPacMan.py:195-229; GameState.getLegalActions, capture.py:101-105). */
 int pmx_observe(pmx_env *env, void *obs_dev, uint8_t *legal_dev, void *stream);

@@ -47,6 +47,7 @@ PROTOTYPES = [
     ("pmx_reset", C.c_int, [_VP, _VP, C.POINTER(StepOut), _VP]),
     ("pmx_step", C.c_int, [_VP, _VP, C.POINTER(StepOut), _VP]),
     ("pmx_step_agent", C.c_int, [_VP, C.c_int, _VP, C.POINTER(StepOut), _VP]),
+    ("pmx_successor", C.c_int, [_VP, C.c_int, _VP, _VP, _VP]),
     ("pmx_observe", C.c_int, [_VP, _VP, _VP, _VP]),
     ("pmx_get_state", C.c_int, [_VP, _I32, _I32, C.POINTER(State), _VP]),
     ("pmx_set_state", C.c_int, [_VP, _I32, _I32, C.POINTER(State), _VP]),

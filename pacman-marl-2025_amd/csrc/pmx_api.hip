@@ -12,6 +12,7 @@
 extern "C" hipError_t pmx_launch_rule(const PmxTickParams *p, int H, hipStream_t st);
 extern "C" hipError_t pmx_launch_rule_agent(const PmxTickParams *p, int H, int agent, hipStream_t st);
 extern "C" hipError_t pmx_launch_reset(const PmxTickParams *p, int H, hipStream_t st);
+extern "C" hipError_t pmx_launch_successor(const PmxTickParams *p, int H, int agent, hipStream_t st);
 extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, int dtype, hipStream_t st);
 extern "C" hipError_t pmx_launch_maze(const PmxLayoutDev *lay_dev, const int16_t *cell_index_dev, int n_cells,
                                       const int8_t *cells_dev, uint8_t *dist_dev, hipStream_t st);
@@ -310,6 +311,17 @@ int pmx_step_agent(pmx_env *env, int agent, const int8_t *actions_dev, const pmx
     HIP_TRY(pmx_launch_rule_agent(&p, env->lay.H, agent, as_stream(stream)));
     env->open_agent = (agent + 1) & 3;
     if (out && out->obs_dev) return launch_expand(env, out->obs_dev, false, agent, as_stream(stream));
+    return PMX_OK;
+}
+
+int pmx_successor(pmx_env *env, int agent, const int8_t *actions_dev, int32_t *score_change_dev, void *stream)
+{
+    if (!env || !actions_dev) return fail(PMX_ERR_INVALID, "pmx_successor: null argument");
+    if (agent < 0 || agent > 3) return fail(PMX_ERR_INVALID, "pmx_successor: agent %d out of range", agent);
+    PmxTickParams p;
+    fill_tick_params(env, p, actions_dev, nullptr);
+    p.score_change = score_change_dev;
+    HIP_TRY(pmx_launch_successor(&p, env->lay.H, agent, as_stream(stream)));
     return PMX_OK;
 }
 

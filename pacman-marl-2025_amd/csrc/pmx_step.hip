@@ -395,6 +395,33 @@ __device__ __forceinline__ void rule_agent_body(const PmxTickParams &p, uint32_t
     store_env(e, c, p.state, p.N, env);
 }
 
+// GameState.generateSuccessor as a stand-alone query (pmx_successor)
+template <int I>
+__device__ __forceinline__ void successor_body(const PmxTickParams &p, uint32_t *lds)
+{
+    Ctx c = make_ctx(p, lds);
+    const int env = blockIdx.x * PMX_RULE_BLOCK + threadIdx.x;
+    if (env >= p.N) return;
+    Env e;
+    load_env(e, c, p.state, p.N, env);
+    bool req_legal;
+    int d_red = 0, d_blue = 0;
+    const int sc = substep<I>(e, c, (int)p.actions[env], req_legal, d_red, d_blue);
+    if (p.score_change) p.score_change[env] = sc;
+    store_env(e, c, p.state, p.N, env);
+}
+
+extern "C" __global__ __launch_bounds__(PMX_RULE_BLOCK) void pmx_successor_kernel(PmxTickParams p, int agent)
+{
+    extern __shared__ uint32_t lds[];
+    switch (agent) {   // wave-uniform
+    case 0: successor_body<0>(p, lds); break;
+    case 1: successor_body<1>(p, lds); break;
+    case 2: successor_body<2>(p, lds); break;
+    default: successor_body<3>(p, lds); break;
+    }
+}
+
 extern "C" __global__ __launch_bounds__(PMX_RULE_BLOCK) void pmx_rule_agent_kernel(PmxTickParams p, int agent)
 {
     extern __shared__ uint32_t lds[];
@@ -582,6 +609,14 @@ extern "C" hipError_t pmx_launch_rule_agent(const PmxTickParams *p, int H, int a
     const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
     const size_t lds = (32 + (size_t)H * PMX_RULE_BLOCK) * sizeof(uint32_t);
     hipLaunchKernelGGL(pmx_rule_agent_kernel, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p, agent);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t pmx_launch_successor(const PmxTickParams *p, int H, int agent, hipStream_t st)
+{
+    const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
+    const size_t lds = (32 + (size_t)H * PMX_RULE_BLOCK) * sizeof(uint32_t);
+    hipLaunchKernelGGL(pmx_successor_kernel, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p, agent);
     return hipGetLastError();
 }
 

@@ -139,11 +139,20 @@ class PmxVecEnv:
                        "pmx_step_agent")
         return self._agent_obs[agent] if want_obs else None
 
-    def observe(self, want_legal=True):
-        """get_Observation of the current state for every emitted agent (gymPacMan.py:195-229)."""
+    def successor(self, agent, actions):
+        """GameState.generateSuccessor (capture.py:107-123) in place on every env; returns scoreChange [N] int32."""
+        a = actions.to(device=self.device, dtype=torch.int8).contiguous()
+        assert a.shape == (self.n_envs,)
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.pmx_observe(self.handle, self.obs.data_ptr(), self.legal.data_ptr() if want_legal else None,
-                                            self._stream()), "pmx_observe")
+            _lib.check(self.lib.pmx_successor(self.handle, int(agent), a.data_ptr(), self.score_change.data_ptr(),
+                                              self._stream()), "pmx_successor")
+        return self.score_change
+
+    def observe(self, want_obs=True, want_legal=True):
+        """get_Observation of the current state for every emitted agent (gymPacMan.py:195-229) and/or the legal masks."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.pmx_observe(self.handle, self.obs.data_ptr() if want_obs else None,
+                                            self.legal.data_ptr() if want_legal else None, self._stream()), "pmx_observe")
         return self.obs, self.legal
 
     # -- measurement ---------------------------------------------------------------------------------------------
