@@ -25,16 +25,38 @@ EMA_DECAY = 0.995                                  # :38
 SHAPING_SCALE = 0.1                                # :34
 
 
+class GroupNorm(nn.Module):
+    """nn.GroupNorm(num_groups, channels) with the same parameters (weight, bias, eps 1e-5), computed as a plain
+    var_mean reduction over each (sample, group) row plus elementwise ops.  torch's native group_norm kernels
+    (RowwiseMoments / ComputePartGradGammaBeta) take 1.7 ms per call on MI355X for a [4096,32,11,14] batch and were
+    45 % of the optimizer step; this form runs on the generic reduce / elementwise kernels and stays in the
+    activation dtype with float32 statistics."""
+
+    def __init__(self, num_groups, num_channels, eps=1e-5):
+        super().__init__()
+        self.num_groups, self.num_channels, self.eps = num_groups, num_channels, eps
+        self.weight = nn.Parameter(torch.ones(num_channels))
+        self.bias = nn.Parameter(torch.zeros(num_channels))
+
+    def forward(self, x):
+        B, C = x.shape[0], x.shape[1]
+        g = x.reshape(B, self.num_groups, -1).float()
+        var, mean = torch.var_mean(g, dim=2, unbiased=False, keepdim=True)
+        y = ((g - mean) * torch.rsqrt(var + self.eps)).reshape(x.shape)
+        shape = (1, C) + (1,) * (x.dim() - 2)
+        return (y * self.weight.view(shape) + self.bias.view(shape)).to(x.dtype)
+
+
 class ResidualBlock(nn.Module):
     """conv3x3 - GroupNorm(4) - GELU - conv3x3 - GroupNorm(4) - (+x) - GELU   (pacman_mappo_resnet.py:49-67)"""
 
     def __init__(self, channels):
         super().__init__()
         self.conv1 = nn.Conv2d(channels, channels, 3, padding=1)
-        self.gn1 = nn.GroupNorm(4, channels)
+        self.gn1 = GroupNorm(4, channels)
         self.act = nn.GELU()
         self.conv2 = nn.Conv2d(channels, channels, 3, padding=1)
-        self.gn2 = nn.GroupNorm(4, channels)
+        self.gn2 = GroupNorm(4, channels)
 
     def forward(self, x):
         y = self.act(self.gn1(self.conv1(x)))
