@@ -65,6 +65,42 @@ def cpu_baseline(layout_rows, length, seconds=12.0):
                       f"({dt:.1f} s on 1 of {os.cpu_count()} host cores)"}
 
 
+def ppo_probe(layname, dev):
+    """The second half of BASELINE.json's metric, measured briefly: MAPPO rollout (env tick + policy inference + shaping)
+    and PPO optimizer steps at the reference's minibatch of 512 samples (pacman_mappo_resnet.py:18), bf16 autocast."""
+    from pmx import trainer
+    n_envs, horizon, mb, steps = 4096, 8, 512, 40
+    tr = trainer.VecMAPPOTrainer(layname, n_envs, horizon=horizon, minibatch=mb, obs_dtype="bfloat16", device=dev, opponent="random")
+    tr.rollout(); tr.compute_gae()                       # warm-up: MIOpen solver search, allocator
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    tr.rollout(); tr.compute_gae()
+    torch.cuda.synchronize(dev)
+    t_roll = time.perf_counter() - t0
+    S = tr.T * tr.N * 2
+    obs = tr.obs_buf.view((S,) + tr.obs_shape)
+    merged = tr.merged_buf.view((tr.T * tr.N,) + tr.obs_shape)
+    perm = torch.randperm(S, device=dev)
+
+    def step(k):
+        i = perm[k * mb:(k + 1) * mb]
+        tr.learner.update_minibatch(tr._net_in(obs[i]), tr._net_in(merged[i // 2]), tr.act_buf.view(S)[i], tr.logp_buf.view(S)[i],
+                                    tr.adv_buf.view(S)[i], tr.ret_buf.view(S)[i])
+    for k in range(5):
+        step(k)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(5, 5 + steps):
+        step(k)
+    torch.cuda.synchronize(dev)
+    t_upd = time.perf_counter() - t0
+    tr.env.close()
+    return {"optimizer_steps_per_s": steps / t_upd, "samples_per_optimizer_step": mb, "train_samples_per_s": steps * mb / t_upd,
+            "rollout_env_steps_per_s": n_envs * horizon / t_roll, "rollout_envs": n_envs, "horizon": horizon,
+            "network": "MAPPOAgent (ResNet actor + transformer critic), bf16 autocast, PyTorch-ROCm ops",
+            "reference_cpu": "about 0.5 optimizer-steps/s and 25 env-steps/s end to end on 8 host cores (SURVEY section 6)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,6 +110,7 @@ def main():
     ap.add_argument("--envs", type=int, default=0, help="override envs per GPU")
     ap.add_argument("--obs", default="float32", choices=sorted(ELEM))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ppo", action="store_true", help="skip the short MAPPO rollout/update probe (N=1 only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -184,8 +221,14 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(lay.text, length)
-        print(json.dumps(line))
     env.close()
+    ppo = None
+    if world == 1 and not args.no_ppo:
+        ppo = ppo_probe(layname, dev)
+    if rank == 0:
+        if ppo is not None:
+            line["ppo"] = ppo
+        print(json.dumps(line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
