@@ -253,6 +253,81 @@ class PPOLearner:
         stats["grad_norm"] = gn.detach()
         return stats
 
+    # ---- hipGraph capture of the whole optimizer step (launch-bound at the reference's minibatch of 512) ----------
+    def capture(self, batch, obs_shape, in_dtype, clip_eps=CLIP_EPS, ent_coef=ENT_COEF_START):
+        """Record zero_grad -> forward -> backward -> (all-reduce) -> clip -> Adam -> EMA for a fixed minibatch shape into
+        a HIP graph.  Scalars that change between updates (lr, clip, entropy coefficient, Adam bias corrections) live in
+        device tensors that the graph reads, so one capture serves the whole schedule."""
+        dev = self.bucket.data.device
+        self._g_in = dict(obs=torch.zeros((batch,) + tuple(obs_shape), dtype=in_dtype, device=dev),
+                          merged=torch.zeros((batch,) + tuple(obs_shape), dtype=in_dtype, device=dev),
+                          act=torch.zeros(batch, dtype=torch.int64, device=dev),
+                          logp=torch.zeros(batch, dtype=torch.float32, device=dev),
+                          adv=torch.randn(batch, dtype=torch.float32, device=dev),
+                          ret=torch.zeros(batch, dtype=torch.float32, device=dev))
+        # lr/bc1, 1/sqrt(bc2), clip_eps, ent_coef as device scalars
+        self._g_sc = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._g_stats = None
+
+        def body():
+            i = self._g_in
+            self.bucket.grad.zero_()
+            if self.autocast_dtype is not None:
+                with torch.autocast(device_type=dev.type, dtype=self.autocast_dtype):
+                    loss, stats = ppo_loss(self.model, i["obs"], i["merged"], i["act"], i["logp"], i["adv"], i["ret"],
+                                           self._g_sc[2], self._g_sc[3])
+            else:
+                loss, stats = ppo_loss(self.model, i["obs"], i["merged"], i["act"], i["logp"], i["adv"], i["ret"],
+                                       self._g_sc[2], self._g_sc[3])
+            loss.backward()
+            if self.world_size > 1:
+                import torch.distributed as dist
+                dist.all_reduce(self.bucket.grad, op=dist.ReduceOp.SUM, group=self.pg)
+                self.bucket.grad.div_(self.world_size)
+            gn = torch.linalg.vector_norm(torch.stack(torch._foreach_norm([p.grad for p in self.bucket.params])))
+            self.bucket.grad.mul_(torch.clamp(MAX_GRAD_NORM / (gn + 1e-6), max=1.0))
+            b1, b2 = self.betas
+            g, p = self.bucket.grad, self.bucket.data
+            self.exp_avg.lerp_(g, 1 - b1)
+            self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
+            denom = (self.exp_avg_sq.sqrt() * self._g_sc[1]).add_(self.eps)
+            p.sub_(self.exp_avg / denom * self._g_sc[0])
+            self.ema.mul_(EMA_DECAY).add_(p, alpha=1 - EMA_DECAY)
+            stats["grad_norm"] = gn
+            return stats
+
+        # warm up on a side stream (allocator, MIOpen solver search), restoring the optimizer state afterwards
+        saved = [t.clone() for t in (self.bucket.data, self.exp_avg, self.exp_avg_sq, self.ema)]
+        self._set_graph_scalars(clip_eps, ent_coef, step=1)
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                body()
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize(dev)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._g_stats = body()
+        for t, v in zip((self.bucket.data, self.exp_avg, self.exp_avg_sq, self.ema), saved):
+            t.copy_(v)
+        self._g_batch = batch
+
+    def _set_graph_scalars(self, clip_eps, ent_coef, step):
+        b1, b2 = self.betas
+        bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+        self._g_sc.copy_(torch.tensor([self.lr / bc1, 1.0 / math.sqrt(bc2), clip_eps, ent_coef], dtype=torch.float32))
+
+    def update_minibatch_graph(self, obs, merged, act, old_logp, adv, ret, clip_eps=CLIP_EPS, ent_coef=ENT_COEF_START):
+        """Same step as update_minibatch, replayed from the captured graph (inputs are copied into its static buffers)."""
+        i = self._g_in
+        i["obs"].copy_(obs); i["merged"].copy_(merged); i["act"].copy_(act)
+        i["logp"].copy_(old_logp); i["adv"].copy_(adv); i["ret"].copy_(ret)
+        self.step_count += 1
+        self._set_graph_scalars(clip_eps, ent_coef, self.step_count)
+        self._graph.replay()
+        return self._g_stats
+
     def ema_state_dict(self):
         """state_dict of the EMA weights with the reference's parameter names (what :647-651 saves)."""
         sd = {k: v.clone() for k, v in self.model.state_dict().items()}

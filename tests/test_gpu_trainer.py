@@ -101,3 +101,25 @@ def test_rollout_gae_update_end_to_end(opponent, dtype):
         assert s["optimizer_steps"] == 2 * (12 * 256 * 2 // 512)
     assert 0.5 < float(tr.stats["entropy"]) <= float(np.log(5)) + 1e-3
     tr.env.close()
+
+
+def test_graph_captured_step_equals_eager_step():
+    """hipGraph replay of the optimizer step against the eager step: same data, fp32, three steps."""
+    from pmx import mappo
+    from test_mappo_cpu import _golden_batch
+    d, meta, obs, merged, act, old_logp, adv, ret = _golden_batch()
+    c = lambda x: x.cuda()
+    torch.manual_seed(3)
+    a = mappo.MAPPOAgent(tuple(obs.shape[1:]), 5, 2).cuda()
+    b = mappo.MAPPOAgent(tuple(obs.shape[1:]), 5, 2).cuda()
+    b.load_state_dict(a.state_dict())
+    la, lb = mappo.PPOLearner(a, lr=2e-4), mappo.PPOLearner(b, lr=2e-4)
+    lb.capture(obs.shape[0], obs.shape[1:], torch.float32)
+    assert torch.equal(la.bucket.data, lb.bucket.data)            # capture restores the optimizer state
+    for k in range(3):
+        sa = la.update_minibatch(c(obs), c(merged), c(act), c(old_logp), c(adv), c(ret), 0.15, 0.02)
+        sb = lb.update_minibatch_graph(c(obs), c(merged), c(act), c(old_logp), c(adv), c(ret), 0.15, 0.02)
+        assert torch.allclose(sa["loss"], sb["loss"], rtol=1e-4, atol=1e-6), k
+        assert torch.allclose(sa["grad_norm"], sb["grad_norm"], rtol=1e-3), k
+    assert torch.allclose(la.bucket.data, lb.bucket.data, rtol=1e-3, atol=2e-5)
+    assert torch.allclose(la.ema, lb.ema, rtol=1e-3, atol=2e-5)

@@ -51,11 +51,15 @@ def run(variant):
         obs, merged = obs.contiguous(memory_format=torch.channels_last), merged.contiguous(memory_format=torch.channels_last)
     act = torch.randint(0, 5, (B,), device=dev)
     logp = torch.full((B,), -1.6, device=dev); adv = torch.randn(B, device=dev); ret = torch.randn(B, device=dev)
+    step = learner.update_minibatch
+    if variant == "graph":
+        learner.capture(B, (8, H, W), torch.bfloat16)
+        step = learner.update_minibatch_graph
     for _ in range(3):
-        learner.update_minibatch(obs, merged, act, logp, adv, ret)
+        step(obs, merged, act, logp, adv, ret)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(args.steps):
-        learner.update_minibatch(obs, merged, act, logp, adv, ret)
+        step(obs, merged, act, logp, adv, ret)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
     # inference
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
