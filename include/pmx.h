@@ -71,6 +71,11 @@ typedef struct {
     int32_t obs_agents;          /* bit i set = emit agent i's observation; 0 means all four (0xF) */
     int32_t device;              /* HIP device ordinal */
     uint32_t seed;               /* key of the PMX_ACTION_RANDOM_LEGAL generator */
+    int32_t n_layouts;           /* 0 or 1: every env plays the one layout above.  L > 1: wall_rows / food_rows / cap_rows
+                                    hold [L][height] rows and starts [L][4][2]; all layouts share width x height
+                                    (gymPacMan's random_layout=True draws a new maze per reset, gymPacMan.py:98-100; here
+                                    each env keeps the maze it is given) */
+    const int32_t *layout_index; /* [n_envs] host array: layout of each env (required when n_layouts > 1) */
 } pmx_config;
 
 /* Outputs of one tick = what gymPacMan.step returns (gymPacMan.py:191-193), batched.  Any pointer may be
@@ -153,6 +158,8 @@ int pmx_set_state(pmx_env *env, int32_t first, int32_t count, const pmx_state *s
  * [n_cells][n_cells] uint8 the shortest 4-neighbour path lengths (255 = unreachable).  *n_cells is a host
  * output available on return (the count is computed on the host); dist_dev may be NULL to query it. */
 int pmx_maze_distances(pmx_env *env, int8_t *cells_dev, uint8_t *dist_dev, int32_t *n_cells, void *stream);
+/* the same for layout `layout` of a multi-layout handle */
+int pmx_maze_distances_layout(pmx_env *env, int32_t layout, int8_t *cells_dev, uint8_t *dist_dev, int32_t *n_cells, void *stream);
 
 /* Measurement hooks (no reference counterpart): between begin and end, every tick records a HIP event pair around
  * its rule-kernel and its expansion-kernel launch on the caller's stream; end synchronises them and returns the

@@ -193,6 +193,40 @@ class BatchEnv:
         self.lib.orc_unpack(self.L.buf, C.byref(p), C.byref(self.S, e * self.ssz))
 
 
+class MultiBatchEnv:
+    """N oracle envs, each with its own (equally sized) layout."""
+
+    def __init__(self, rows_list, layout_index, length=299, legal_reward=True, defence_reward=True, auto_reset=True, seed=0):
+        self.lib = lib()
+        self.Ls = [Layout(r) for r in rows_list]
+        lsz = self.lib.orc_sizeof_layout()
+        self.lbuf = C.create_string_buffer(lsz * len(self.Ls))
+        for k, L in enumerate(self.Ls):
+            C.memmove(C.byref(self.lbuf, k * lsz), L.buf, lsz)
+        self.index = np.ascontiguousarray(layout_index, np.int32)
+        self.n = n = len(self.index)
+        self.H, self.W = self.Ls[0].H, self.Ls[0].W
+        self.cfg = Cfg(int(length), int(bool(legal_reward)), int(bool(defence_reward)), int(seed))
+        self.ssz = self.lib.orc_sizeof_state()
+        self.S = C.create_string_buffer(self.ssz * n)
+        self.auto_reset = int(auto_reset)
+        for e in range(n):
+            self.lib.orc_reset(C.byref(self.lbuf, int(self.index[e]) * lsz), C.byref(self.S, e * self.ssz))
+        self.reward = np.zeros((n, 2), np.float64)
+        self.done = np.zeros(n, np.uint8)
+        self.legal = np.zeros((n, 4), np.uint8)
+        self.score_change = np.zeros(n, np.int32)
+        self.score = np.zeros(n, np.int32)
+        self.agent = np.zeros((n, 4), np.uint32)
+
+    def tick(self, actions, obs=None):
+        a = np.ascontiguousarray(actions, np.int8)
+        self.lib.orc_tick_batch_multi(self.lbuf, self.index.ctypes, C.byref(self.cfg), self.S, self.n, a.ctypes,
+                                      obs.ctypes if obs is not None else None, self.reward.ctypes, self.done.ctypes,
+                                      self.legal.ctypes, self.score_change.ctypes, self.auto_reset, self.score.ctypes,
+                                      self.agent.ctypes)
+
+
 def maze_distances(rows):
     L = Layout(rows)
     cells = np.zeros((MAXD * MAXD, 2), np.int8)

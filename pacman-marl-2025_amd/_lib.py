@@ -21,7 +21,8 @@ class Config(C.Structure):
                 ("cap_rows", C.POINTER(C.c_uint32)), ("starts", C.POINTER(C.c_int8)),
                 ("n_envs", C.c_int32), ("length", C.c_int32), ("legal_reward", C.c_int32),
                 ("defence_reward", C.c_int32), ("auto_reset", C.c_int32), ("obs_dtype", C.c_int32),
-                ("obs_agents", C.c_int32), ("device", C.c_int32), ("seed", C.c_uint32)]
+                ("obs_agents", C.c_int32), ("device", C.c_int32), ("seed", C.c_uint32), ("n_layouts", C.c_int32),
+                ("layout_index", C.POINTER(C.c_int32))]
 
 
 class StepOut(C.Structure):
@@ -52,6 +53,7 @@ PROTOTYPES = [
     ("pmx_get_state", C.c_int, [_VP, _I32, _I32, C.POINTER(State), _VP]),
     ("pmx_set_state", C.c_int, [_VP, _I32, _I32, C.POINTER(State), _VP]),
     ("pmx_maze_distances", C.c_int, [_VP, _VP, _VP, C.POINTER(_I32), _VP]),
+    ("pmx_maze_distances_layout", C.c_int, [_VP, _I32, _VP, _VP, C.POINTER(_I32), _VP]),
     ("pmx_profile_begin", C.c_int, [_VP, _I32]),
     ("pmx_profile_end", C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(_I32), C.POINTER(C.c_double), C.POINTER(_I32)]),
     ("pmx_gae", C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, C.c_double, C.c_double, _VP, _VP, _VP]),

@@ -17,9 +17,18 @@ extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, int dtype, hip
 extern "C" hipError_t pmx_launch_maze(const PmxLayoutDev *lay_dev, const int16_t *cell_index_dev, int n_cells,
                                       const int8_t *cells_dev, uint8_t *dist_dev, hipStream_t st);
 
+struct pmx_layout_host {
+    PmxLayoutDev dev;
+    std::vector<int8_t> cells;       // open cells in asList(False) order
+    std::vector<int16_t> cell_index;
+};
+
 struct pmx_env {
     pmx_config cfg;
-    PmxLayoutDev lay;          // host copy
+    PmxLayoutDev lay;          // host copy of layout 0 (dimensions are common to all layouts)
+    std::vector<pmx_layout_host> layouts;
+    std::vector<int32_t> layout_index;   // per env (empty: one layout)
+    int32_t *layout_idx_dev;
     PmxLayoutDev *lay_dev;
     int8_t *dump_dev;
     uint32_t *state_dev;
@@ -28,8 +37,6 @@ struct pmx_env {
     int emit[4];
     int elem_bytes;
     int open_agent;            // next agent expected by pmx_step_agent
-    std::vector<int8_t> cells; // open cells in asList(False) order
-    std::vector<int16_t> cell_index;
     // optional per-kernel timing (pmx_profile_begin/end): pairs of events around each launch
     bool profiling;
     std::vector<hipEvent_t> ev_rule, ev_expand;
@@ -90,6 +97,7 @@ void fill_tick_params(pmx_env *env, PmxTickParams &p, const int8_t *actions, con
     p.state = env->state_dev;
     p.snap = env->snap_dev;
     p.lay = env->lay_dev;
+    p.layout_idx = env->layout_idx_dev;
     p.dump = env->dump_dev;
     p.actions = actions;
     p.N = env->cfg.n_envs;
@@ -128,6 +136,7 @@ int launch_expand(pmx_env *env, void *obs, bool from_snapshots, int single_agent
     for (int a = 0; a < 4; ++a)
         x.snap[a] = (from_snapshots && a < 3) ? env->snap_dev + a * snap_sz : env->state_dev;
     x.lay = env->lay_dev;
+    x.layout_idx = env->layout_idx_dev;
     x.obs = obs;
     x.N = env->cfg.n_envs;
     x.single_agent = single_agent;
@@ -152,6 +161,64 @@ extern "C" {
 int pmx_version(void) { return PMX_VERSION; }
 const char *pmx_last_error(void) { return g_err; }
 
+// layout.py:95-130 output -> validated device record
+static int build_layout(const pmx_config *cfg, int li, pmx_layout_host &out)
+{
+    const int W = cfg->width, H = cfg->height;
+    const uint32_t *wall_rows = cfg->wall_rows + (size_t)li * H, *food_rows = cfg->food_rows + (size_t)li * H;
+    const uint32_t *cap_rows = cfg->cap_rows + (size_t)li * H;
+    const int8_t *starts = cfg->starts + (size_t)li * 8;
+    const uint32_t full = W == 32 ? 0xFFFFFFFFu : ((1u << W) - 1u);
+    PmxLayoutDev &L = out.dev;
+    std::memset(&L, 0, sizeof(L));
+    L.W = W; L.H = H; L.half = W / 2;
+    L.lo_mask = (1u << L.half) - 1u;
+    L.hi_mask = full & ~L.lo_mask;
+    int n_caps = 0;
+    uint16_t capslots[4] = { 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF };
+    for (int y = 0; y < H; ++y) {
+        const uint32_t w = wall_rows[y], f = food_rows[y], c = cap_rows[y];
+        if ((w | f | c) & ~full) return fail(PMX_ERR_INVALID, "layout %d row %d has bits beyond the width", li, y);
+        if ((w & f) || (w & c) || (f & c)) return fail(PMX_ERR_INVALID, "layout %d row %d: wall/food/capsule overlap", li, y);
+        const bool border = (y == 0 || y == H - 1);
+        if (border ? (w != full) : (!(w & 1u) || !((w >> (W - 1)) & 1u)))
+            return fail(PMX_ERR_INVALID, "layout %d row %d: the layout must be enclosed by walls (game.py:335-350 indexes neighbours)", li, y);
+        L.walls[y] = w;
+        L.food0[y] = f;
+        L.total_food += __builtin_popcount(f);
+        for (int x = 0; x < W; ++x)
+            if ((c >> x) & 1u) {
+                if (n_caps == PMX_MAX_CAPSULES) return fail(PMX_ERR_UNSUPPORTED, "layout %d: more than %d capsules", li, PMX_MAX_CAPSULES);
+                capslots[n_caps++] = (uint16_t)(x | (y << 8));
+            }
+    }
+    L.capw0[0] = capslots[0] | ((uint32_t)capslots[1] << 16);
+    L.capw0[1] = capslots[2] | ((uint32_t)capslots[3] << 16);
+    for (int i = 0; i < 4; ++i) {
+        const int sx = starts[2 * i], sy = starts[2 * i + 1];
+        if (sx <= 0 || sy <= 0 || sx >= W - 1 || sy >= H - 1 || ((L.walls[sy] >> sx) & 1u))
+            return fail(PMX_ERR_INVALID, "layout %d: agent %d start (%d,%d) is not an open interior cell", li, i, sx, sy);
+        const bool red = 2 * sx < W;   // capture.py:325-330
+        if (red != ((i & 1) == 0))
+            return fail(PMX_ERR_UNSUPPORTED, "layout %d: agent %d starts on the %s half: gymPacMan.py:150,185,210 hard-codes red = agents 0,2",
+                        li, i, red ? "red" : "blue");
+        L.startx[i] = sx; L.starty[i] = sy;
+    }
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x)
+            if ((L.walls[y] >> x) & 1u) L.wall_stream[(y * W + x) >> 5] |= 1u << ((y * W + x) & 31);
+    out.cell_index.assign(32 * 32, -1);
+    out.cells.clear();
+    for (int x = 0; x < W; ++x)           // Grid.asList(False): x outer, y inner (game.py:225-230)
+        for (int y = 0; y < H; ++y)
+            if (!((L.walls[y] >> x) & 1u)) {
+                out.cell_index[y * 32 + x] = (int16_t)(out.cells.size() / 2);
+                out.cells.push_back((int8_t)x);
+                out.cells.push_back((int8_t)y);
+            }
+    return PMX_OK;
+}
+
 int pmx_create(const pmx_config *cfg, pmx_env **out)
 {
     if (!cfg || !out) return fail(PMX_ERR_INVALID, "pmx_create: null argument");
@@ -165,81 +232,54 @@ int pmx_create(const pmx_config *cfg, pmx_env **out)
     if (cfg->obs_dtype < PMX_OBS_F32 || cfg->obs_dtype > PMX_OBS_U8) return fail(PMX_ERR_INVALID, "bad obs_dtype");
     if (cfg->obs_dtype == PMX_OBS_U8 && ((H * W) & 1))
         return fail(PMX_ERR_UNSUPPORTED, "uint8 observations need an even number of cells (16-byte rows of the stream)");
-    const uint32_t full = W == 32 ? 0xFFFFFFFFu : ((1u << W) - 1u);
-    PmxLayoutDev L;
-    std::memset(&L, 0, sizeof(L));
-    L.W = W; L.H = H; L.half = W / 2;
-    L.lo_mask = (1u << L.half) - 1u;
-    L.hi_mask = full & ~L.lo_mask;
-    int n_caps = 0;
-    uint16_t capslots[4] = { 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF };
-    for (int y = 0; y < H; ++y) {
-        const uint32_t w = cfg->wall_rows[y], f = cfg->food_rows[y], c = cfg->cap_rows[y];
-        if ((w | f | c) & ~full) return fail(PMX_ERR_INVALID, "row %d has bits beyond the width", y);
-        if ((w & f) || (w & c) || (f & c)) return fail(PMX_ERR_INVALID, "row %d: wall/food/capsule overlap", y);
-        const bool border = (y == 0 || y == H - 1);
-        if (border ? (w != full) : (!(w & 1u) || !((w >> (W - 1)) & 1u)))
-            return fail(PMX_ERR_INVALID, "row %d: the layout must be enclosed by walls (game.py:335-350 indexes neighbours)", y);
-        L.walls[y] = w;
-        L.food0[y] = f;
-        L.total_food += __builtin_popcount(f);
-        for (int x = 0; x < W; ++x)
-            if ((c >> x) & 1u) {
-                if (n_caps == PMX_MAX_CAPSULES) return fail(PMX_ERR_UNSUPPORTED, "more than %d capsules", PMX_MAX_CAPSULES);
-                capslots[n_caps++] = (uint16_t)(x | (y << 8));
-            }
-    }
-    L.capw0[0] = capslots[0] | ((uint32_t)capslots[1] << 16);
-    L.capw0[1] = capslots[2] | ((uint32_t)capslots[3] << 16);
-    for (int i = 0; i < 4; ++i) {
-        const int sx = cfg->starts[2 * i], sy = cfg->starts[2 * i + 1];
-        if (sx <= 0 || sy <= 0 || sx >= W - 1 || sy >= H - 1 || ((L.walls[sy] >> sx) & 1u))
-            return fail(PMX_ERR_INVALID, "agent %d start (%d,%d) is not an open interior cell", i, sx, sy);
-        const bool red = 2 * sx < W;   // capture.py:325-330
-        if (red != ((i & 1) == 0))
-            return fail(PMX_ERR_UNSUPPORTED, "agent %d starts on the %s half: gymPacMan.py:150,185,210 hard-codes red = agents 0,2",
-                        i, red ? "red" : "blue");
-        L.startx[i] = sx; L.starty[i] = sy;
-    }
-    for (int y = 0; y < H; ++y)
-        for (int x = 0; x < W; ++x)
-            if ((L.walls[y] >> x) & 1u) L.wall_stream[(y * W + x) >> 5] |= 1u << ((y * W + x) & 31);
-    const std::vector<int8_t> dump = dump_order(std::max(W, H));
-    L.n_dump = (int)(dump.size() / 2);
+    const int n_layouts = cfg->n_layouts > 1 ? cfg->n_layouts : 1;
+    if (n_layouts > 1 && !cfg->layout_index) return fail(PMX_ERR_INVALID, "n_layouts > 1 needs layout_index");
 
     pmx_env *env = new (std::nothrow) pmx_env();
     if (!env) return fail(PMX_ERR_NOMEM, "host allocation failed");
+    env->layouts.resize(n_layouts);
+    for (int li = 0; li < n_layouts; ++li) {
+        int rc = build_layout(cfg, li, env->layouts[li]);
+        if (rc != PMX_OK) { delete env; return rc; }
+    }
+    const std::vector<int8_t> dump = dump_order(std::max(W, H));
+    for (auto &l : env->layouts) l.dev.n_dump = (int)(dump.size() / 2);
     env->cfg = *cfg;
     env->cfg.wall_rows = env->cfg.food_rows = env->cfg.cap_rows = nullptr;
     env->cfg.starts = nullptr;
-    env->lay = L;
+    env->cfg.layout_index = nullptr;
+    env->cfg.n_layouts = n_layouts;
+    env->lay = env->layouts[0].dev;
     env->open_agent = 0;
+    if (n_layouts > 1) {
+        env->layout_index.assign(cfg->layout_index, cfg->layout_index + cfg->n_envs);
+        for (int32_t v : env->layout_index)
+            if (v < 0 || v >= n_layouts) { delete env; return fail(PMX_ERR_INVALID, "layout_index entry %d outside [0,%d)", v, n_layouts); }
+    }
     const int mask = (cfg->obs_agents & 0xF) ? (cfg->obs_agents & 0xF) : 0xF;
     env->cfg.obs_agents = mask;
     env->n_emit = 0;
     for (int i = 0; i < 4; ++i)
         if ((mask >> i) & 1) env->emit[env->n_emit++] = i;
     env->elem_bytes = cfg->obs_dtype == PMX_OBS_F32 ? 4 : (cfg->obs_dtype == PMX_OBS_BF16 ? 2 : 1);
-    env->cell_index.assign(32 * 32, -1);
-    for (int x = 0; x < W; ++x)           // Grid.asList(False): x outer, y inner (game.py:225-230)
-        for (int y = 0; y < H; ++y)
-            if (!((L.walls[y] >> x) & 1u)) {
-                env->cell_index[y * 32 + x] = (int16_t)(env->cells.size() / 2);
-                env->cells.push_back((int8_t)x);
-                env->cells.push_back((int8_t)y);
-            }
     env->lay_dev = nullptr; env->dump_dev = nullptr; env->state_dev = nullptr; env->snap_dev = nullptr;
+    env->layout_idx_dev = nullptr;
     env->profiling = false; env->ev_rule_used = env->ev_expand_used = 0;
 
     hipError_t e = hipSetDevice(cfg->device);
     const size_t N = (size_t)cfg->n_envs;
-    if (e == hipSuccess) e = hipMalloc((void **)&env->lay_dev, sizeof(PmxLayoutDev));
+    std::vector<PmxLayoutDev> recs;
+    for (auto &l : env->layouts) recs.push_back(l.dev);
+    if (e == hipSuccess) e = hipMalloc((void **)&env->lay_dev, sizeof(PmxLayoutDev) * recs.size());
     if (e == hipSuccess) e = hipMalloc((void **)&env->dump_dev, dump.size());
     if (e == hipSuccess) e = hipMalloc((void **)&env->state_dev, PMX_STATE_WORDS(H) * N * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&env->snap_dev, 3 * (size_t)PMX_SNAP_WORDS(H) * N * sizeof(uint32_t));
+    if (e == hipSuccess && n_layouts > 1) e = hipMalloc((void **)&env->layout_idx_dev, N * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemset(env->state_dev, 0, PMX_STATE_WORDS(H) * N * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemcpy(env->lay_dev, &L, sizeof(L), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(env->lay_dev, recs.data(), sizeof(PmxLayoutDev) * recs.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(env->dump_dev, dump.data(), dump.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_layouts > 1)
+        e = hipMemcpy(env->layout_idx_dev, env->layout_index.data(), N * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         pmx_destroy(env);
         return fail(e == hipErrorOutOfMemory ? PMX_ERR_NOMEM : PMX_ERR_HIP, "pmx_create: %s", hipGetErrorString(e));
@@ -258,6 +298,7 @@ int pmx_destroy(pmx_env *env)
     if (env->dump_dev) (void)hipFree(env->dump_dev);
     if (env->state_dev) (void)hipFree(env->state_dev);
     if (env->snap_dev) (void)hipFree(env->snap_dev);
+    if (env->layout_idx_dev) (void)hipFree(env->layout_idx_dev);
     for (hipEvent_t e : env->ev_rule) (void)hipEventDestroy(e);
     for (hipEvent_t e : env->ev_expand) (void)hipEventDestroy(e);
     delete env;
@@ -430,11 +471,12 @@ int pmx_set_state(pmx_env *env, int32_t first, int32_t count, const pmx_state *s
     std::vector<uint32_t> buf((size_t)words * count, 0);
     for (int k = 0; k < count; ++k) {
         const pmx_state &s = states[k];
+        const PmxLayoutDev &lay = env->layouts[env->layout_index.empty() ? 0 : env->layout_index[first + k]].dev;
         auto word = [&](int w) -> uint32_t & { return buf[(size_t)w * count + k]; };
         uint16_t slots[4] = { 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF };
         int nc = 0;
         for (int y = 0; y < H; ++y) {
-            if ((s.food[y] | s.caps[y]) & env->lay.walls[y]) return fail(PMX_ERR_INVALID, "state %d: food/capsule inside a wall (row %d)", k, y);
+            if ((s.food[y] | s.caps[y]) & lay.walls[y]) return fail(PMX_ERR_INVALID, "state %d: food/capsule inside a wall (row %d)", k, y);
             word(y) = s.food[y];
             for (int x = 0; x < W; ++x)
                 if ((s.caps[y] >> x) & 1u) {
@@ -444,7 +486,7 @@ int pmx_set_state(pmx_env *env, int32_t first, int32_t count, const pmx_state *s
         }
         for (int i = 0; i < 4; ++i) {
             const int x = s.pos[i][0], y = s.pos[i][1];
-            if (x <= 0 || y <= 0 || x >= W - 1 || y >= H - 1 || ((env->lay.walls[y] >> x) & 1u))
+            if (x <= 0 || y <= 0 || x >= W - 1 || y >= H - 1 || ((lay.walls[y] >> x) & 1u))
                 return fail(PMX_ERR_INVALID, "state %d: agent %d at (%d,%d) is not on an open interior cell", k, i, x, y);
             if (s.dir[i] < 0 || s.dir[i] > 4 || s.carry[i] > 0xFFF || s.ret[i] > 0xFFF)
                 return fail(PMX_ERR_INVALID, "state %d: agent %d field out of range", k, i);
@@ -464,24 +506,34 @@ int pmx_set_state(pmx_env *env, int32_t first, int32_t count, const pmx_state *s
     return PMX_OK;
 }
 
-int pmx_maze_distances(pmx_env *env, int8_t *cells_dev, uint8_t *dist_dev, int32_t *n_cells, void *stream)
+int pmx_maze_distances_layout(pmx_env *env, int32_t layout, int8_t *cells_dev, uint8_t *dist_dev, int32_t *n_cells, void *stream)
 {
     if (!env) return fail(PMX_ERR_INVALID, "null env");
-    const int n = (int)(env->cells.size() / 2);
+    if (layout < 0 || layout >= (int32_t)env->layouts.size()) return fail(PMX_ERR_INVALID, "layout %d out of range", layout);
+    const pmx_layout_host &lh = env->layouts[layout];
+    const int n = (int)(lh.cells.size() / 2);
     if (n_cells) *n_cells = n;
-    if (cells_dev) HIP_TRY(hipMemcpyAsync(cells_dev, env->cells.data(), env->cells.size(), hipMemcpyHostToDevice, as_stream(stream)));
-    if (!dist_dev) return PMX_OK;
+    if (cells_dev) HIP_TRY(hipMemcpyAsync(cells_dev, lh.cells.data(), lh.cells.size(), hipMemcpyHostToDevice, as_stream(stream)));
+    if (!dist_dev) {
+        if (cells_dev) HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+        return PMX_OK;
+    }
     if (!cells_dev) return fail(PMX_ERR_INVALID, "pmx_maze_distances: cells_dev is required with dist_dev");
     int16_t *idx_dev = nullptr;
-    HIP_TRY(hipMallocAsync((void **)&idx_dev, env->cell_index.size() * sizeof(int16_t), as_stream(stream)));
-    HIP_TRY(hipMemcpyAsync(idx_dev, env->cell_index.data(), env->cell_index.size() * sizeof(int16_t), hipMemcpyHostToDevice,
+    HIP_TRY(hipMallocAsync((void **)&idx_dev, lh.cell_index.size() * sizeof(int16_t), as_stream(stream)));
+    HIP_TRY(hipMemcpyAsync(idx_dev, lh.cell_index.data(), lh.cell_index.size() * sizeof(int16_t), hipMemcpyHostToDevice,
                            as_stream(stream)));
-    hipError_t e = pmx_launch_maze(env->lay_dev, idx_dev, n, cells_dev, dist_dev, as_stream(stream));
+    hipError_t e = pmx_launch_maze(env->lay_dev + layout, idx_dev, n, cells_dev, dist_dev, as_stream(stream));
     // the host vectors outlive the async copies only if we wait for them here
     HIP_TRY(hipStreamSynchronize(as_stream(stream)));
     HIP_TRY(hipFreeAsync(idx_dev, as_stream(stream)));
     if (e != hipSuccess) return fail(PMX_ERR_HIP, "pmx_maze_distances: %s", hipGetErrorString(e));
     return PMX_OK;
+}
+
+int pmx_maze_distances(pmx_env *env, int8_t *cells_dev, uint8_t *dist_dev, int32_t *n_cells, void *stream)
+{
+    return pmx_maze_distances_layout(env, 0, cells_dev, dist_dev, n_cells, stream);
 }
 
 }  // extern "C"

@@ -49,7 +49,8 @@ struct PmxLayoutDev {
 struct PmxTickParams {
     uint32_t *state;             // [PMX_STATE_WORDS][N]
     uint32_t *snap;              // [3][PMX_SNAP_WORDS][N] states after sub-steps 0,1,2
-    const PmxLayoutDev *lay;
+    const PmxLayoutDev *lay;     // [n_layouts]
+    const int32_t *layout_idx;   // [N] layout of each env, or NULL when the handle has one layout
     const int8_t *dump;          // [n_dump][2] BFS visit order of dumpFoodFromDeath
     const int8_t *actions;
     int32_t N, length, legal_reward, defence_reward, auto_reset;
@@ -66,7 +67,8 @@ struct PmxTickParams {
 
 struct PmxExpandParams {
     const uint32_t *snap[4];     // per AGENT: base of the snapshot its planes are encoded from
-    const PmxLayoutDev *lay;
+    const PmxLayoutDev *lay;     // [n_layouts]
+    const int32_t *layout_idx;   // [N] or NULL
     void *obs;                   // [N][n_emit][8][H][W]
     int32_t N, n_emit;
     int32_t emit[4];             // agent index of each emitted slot

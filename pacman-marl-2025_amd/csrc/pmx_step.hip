@@ -12,6 +12,8 @@
 // N*4 wavefronts of perfectly coalesced stores regardless of N.
 #include "pmx_device.h"
 
+#define PMX_MAX_H_LDS 32   // per-lane wall columns (multi-layout handles) start after room for 32 food rows
+
 namespace {
 
 struct Env {
@@ -28,7 +30,8 @@ struct Acc {
 };
 
 struct Ctx {
-    const uint32_t *wl;   // LDS: wall rows of the layout
+    const uint32_t *wl;   // LDS: wall rows, row y at wl[y * wls] (wls = 1: one shared layout; PMX_RULE_BLOCK: per-lane layouts)
+    int wls;
     uint32_t *fd;         // LDS: this lane's food column, row y at fd[y * PMX_RULE_BLOCK]
     const PmxLayoutDev *L;
     const int8_t *dump;
@@ -55,9 +58,9 @@ __device__ __forceinline__ void unpack_b(Env &e, int i, uint32_t w)
 }
 
 // capture.py:453-461 + game.py:335-350: bit a = action a legal (0 N, 1 E, 2 S, 3 W, 4 Stop)
-__device__ __forceinline__ int legal_mask(const uint32_t *wl, int x, int y)
+__device__ __forceinline__ int legal_mask(const uint32_t *wl, int wls, int x, int y)
 {
-    uint32_t r0 = ~wl[y], rn = ~wl[y + 1], rs = ~wl[y - 1];
+    uint32_t r0 = ~wl[y * wls], rn = ~wl[(y + 1) * wls], rs = ~wl[(y - 1) * wls];
     return (int)(((rn >> x) & 1u) | (((r0 >> (x + 1)) & 1u) << 1) | (((rs >> x) & 1u) << 2) |
                  (((r0 >> (x - 1)) & 1u) << 3) | (((r0 >> x) & 1u) << 4));
 }
@@ -90,7 +93,7 @@ __device__ __forceinline__ void dump_food(Env &e, const Ctx &c, int who_x, int w
     for (int k = 0; k < c.n_dump && num > 0; ++k) {
         int X = who_x + c.dump[2 * k], Y = who_y + c.dump[2 * k + 1];
         if (X <= 0 || Y <= 0 || X >= c.W || Y >= c.H) continue;          // :609
-        if ((c.wl[Y] >> X) & 1u) continue;                                // :612
+        if ((c.wl[Y * c.wls] >> X) & 1u) continue;                                // :612
         uint32_t row = c.fd[Y * PMX_RULE_BLOCK];
         if ((row >> X) & 1u) continue;                                    // :614
         if ((2 * X < c.W) != side_red) continue;                          // :618
@@ -161,7 +164,7 @@ __device__ __forceinline__ int substep(Env &e, const Ctx &c, int action, bool &r
     constexpr bool RED = (I % 2) == 0;
     constexpr int O1 = RED ? 1 : 0, O2 = O1 + 2;
     // ---- applyAction capture.py:468-517
-    const int legal = legal_mask(c.wl, e.x[I], e.y[I]);
+    const int legal = legal_mask(c.wl, c.wls, e.x[I], e.y[I]);
     if (action == -2) action = random_legal(legal, c.rng_key, e.ticks, I);
     req_legal = (action >= 0) && (action <= 4) && ((legal >> (action & 7)) & 1);
     if (!req_legal) action = 4;                                           // :473-474
@@ -319,7 +322,7 @@ __device__ __forceinline__ void tick_finish(Env &e, Acc &a, const Ctx &c, const 
     if (p.legal) {
         uint32_t m = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) m |= (uint32_t)legal_mask(c.wl, e.x[i], e.y[i]) << (8 * i);
+        for (int i = 0; i < 4; ++i) m |= (uint32_t)legal_mask(c.wl, c.wls, e.x[i], e.y[i]) << (8 * i);
         reinterpret_cast<uint32_t *>(p.legal)[env] = m;
     }
 }
@@ -327,14 +330,21 @@ __device__ __forceinline__ void tick_finish(Env &e, Acc &a, const Ctx &c, const 
 __device__ __forceinline__ Ctx make_ctx(const PmxTickParams &p, uint32_t *lds)
 {
     Ctx c;
-    c.L = p.lay;
-    c.W = p.lay->W; c.H = p.lay->H; c.half = p.lay->half; c.n_dump = p.lay->n_dump;
+    const int env0 = blockIdx.x * PMX_RULE_BLOCK + threadIdx.x;
+    const bool multi = p.layout_idx != nullptr;
+    c.L = p.lay + ((multi && env0 < p.N) ? p.layout_idx[env0] : 0);
+    c.W = p.lay->W; c.H = p.lay->H; c.half = p.lay->half; c.n_dump = p.lay->n_dump;   // identical in every layout of a handle
     c.dump = p.dump;
     c.legal_reward = p.legal_reward; c.defence_reward = p.defence_reward;
-    c.wl = lds;
+    c.wl = multi ? lds + 32 + PMX_MAX_H_LDS * PMX_RULE_BLOCK + threadIdx.x : lds;
+    c.wls = multi ? PMX_RULE_BLOCK : 1;
     c.fd = lds + 32 + threadIdx.x;
     c.rng_key = p.seed ^ ((uint32_t)(blockIdx.x * PMX_RULE_BLOCK + threadIdx.x) * 0x9E3779B1u);
     if (threadIdx.x < 32) lds[threadIdx.x] = threadIdx.x < (unsigned)c.H ? p.lay->walls[threadIdx.x] : 0xFFFFFFFFu;
+    if (multi) {   // per-env layouts: every lane keeps its own wall column next to its food column
+        uint32_t *w = lds + 32 + PMX_MAX_H_LDS * PMX_RULE_BLOCK + threadIdx.x;
+        for (int y = 0; y < 32; ++y) w[y * PMX_RULE_BLOCK] = y < c.H ? c.L->walls[y] : 0xFFFFFFFFu;
+    }
     __syncthreads();
     return c;
 }
@@ -452,7 +462,7 @@ extern "C" __global__ __launch_bounds__(PMX_RULE_BLOCK) void pmx_reset_kernel(Pm
     if (p.legal) {
         uint32_t m = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) m |= (uint32_t)legal_mask(c.wl, e.x[i], e.y[i]) << (8 * i);
+        for (int i = 0; i < 4; ++i) m |= (uint32_t)legal_mask(c.wl, c.wls, e.x[i], e.y[i]) << (8 * i);
         reinterpret_cast<uint32_t *>(p.legal)[env] = m;
     }
 }
@@ -529,8 +539,7 @@ __global__ __launch_bounds__(PMX_BLOCK) void pmx_expand_kernel(PmxExpandParams p
     __shared__ uint32_t tab[4][8 * 32 * 32 / 32 + 8];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const PmxLayoutDev *L = p.lay;
-    const int W = L->W, H = L->H;
+    const int W = p.lay->W, H = p.lay->H;
     const int HW = H * W;
     const long total = (long)p.N * p.n_emit;
     long blk = blockIdx.x;
@@ -549,6 +558,7 @@ __global__ __launch_bounds__(PMX_BLOCK) void pmx_expand_kernel(PmxExpandParams p
     const uint32_t *S = p.snap[agent] + env;
     const size_t N = (size_t)p.N;
     uint32_t *T = tab[wave];
+    const PmxLayoutDev *L = p.lay + (p.layout_idx ? p.layout_idx[env] : 0);
 
     // issue the snapshot loads first, their latency hides behind the table initialisation
     const uint32_t food = lane < H ? S[(size_t)lane * N] : 0u;
@@ -606,7 +616,7 @@ __global__ __launch_bounds__(PMX_BLOCK) void pmx_expand_kernel(PmxExpandParams p
 extern "C" hipError_t pmx_launch_rule(const PmxTickParams *p, int H, hipStream_t st)
 {
     const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
-    const size_t lds = (32 + (size_t)H * PMX_RULE_BLOCK) * sizeof(uint32_t);
+    const size_t lds = (p->layout_idx ? 32 + (size_t)(PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)H * PMX_RULE_BLOCK) * sizeof(uint32_t);
     hipLaunchKernelGGL(pmx_rule_kernel, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p);
     return hipGetLastError();
 }
@@ -614,7 +624,7 @@ extern "C" hipError_t pmx_launch_rule(const PmxTickParams *p, int H, hipStream_t
 extern "C" hipError_t pmx_launch_rule_agent(const PmxTickParams *p, int H, int agent, hipStream_t st)
 {
     const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
-    const size_t lds = (32 + (size_t)H * PMX_RULE_BLOCK) * sizeof(uint32_t);
+    const size_t lds = (p->layout_idx ? 32 + (size_t)(PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)H * PMX_RULE_BLOCK) * sizeof(uint32_t);
     hipLaunchKernelGGL(pmx_rule_agent_kernel, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p, agent);
     return hipGetLastError();
 }
@@ -622,7 +632,7 @@ extern "C" hipError_t pmx_launch_rule_agent(const PmxTickParams *p, int H, int a
 extern "C" hipError_t pmx_launch_successor(const PmxTickParams *p, int H, int agent, hipStream_t st)
 {
     const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
-    const size_t lds = (32 + (size_t)H * PMX_RULE_BLOCK) * sizeof(uint32_t);
+    const size_t lds = (p->layout_idx ? 32 + (size_t)(PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)H * PMX_RULE_BLOCK) * sizeof(uint32_t);
     hipLaunchKernelGGL(pmx_successor_kernel, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p, agent);
     return hipGetLastError();
 }
@@ -630,7 +640,7 @@ extern "C" hipError_t pmx_launch_successor(const PmxTickParams *p, int H, int ag
 extern "C" hipError_t pmx_launch_reset(const PmxTickParams *p, int H, hipStream_t st)
 {
     const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
-    const size_t lds = (32 + (size_t)H * PMX_RULE_BLOCK) * sizeof(uint32_t);
+    const size_t lds = (p->layout_idx ? 32 + (size_t)(PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)H * PMX_RULE_BLOCK) * sizeof(uint32_t);
     hipLaunchKernelGGL(pmx_reset_kernel, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p);
     return hipGetLastError();
 }

@@ -24,10 +24,15 @@ def legal_list(mask):
 
 class PmxVecEnv:
     def __init__(self, layout, n_envs, length=299, reward_forLegalAction=True, defenceReward=True, auto_reset=True,
-                 obs_dtype="float32", obs_agents=(0, 1, 2, 3), device="cuda:0", seed=0):
+                 obs_dtype="float32", obs_agents=(0, 1, 2, 3), device="cuda:0", seed=0, layout_index=None):
         if not torch.cuda.is_available():
             raise _lib.PmxError("PmxVecEnv needs a GPU: the product has no CPU path")
         self.lib = _lib.load()
+        # `layout` may be one layout (name / Layout) or a list of equally sized Layouts with `layout_index` [n_envs]
+        layouts = None
+        if isinstance(layout, (list, tuple)):
+            layouts = list(layout)
+            layout = layouts[0]
         if isinstance(layout, str):
             lay = get_layout(layout)
             if lay is None:
@@ -35,6 +40,9 @@ class PmxVecEnv:
             layout = lay
         assert isinstance(layout, Layout)
         self.layout = layout
+        self.layouts = layouts if layouts is not None else [layout]
+        if any((l.width, l.height) != (layout.width, layout.height) for l in self.layouts):
+            raise ValueError("all layouts of one PmxVecEnv must have the same width and height")
         self.n_envs = int(n_envs)
         self.length = int(length)
         self.device = torch.device(device)
@@ -42,8 +50,18 @@ class PmxVecEnv:
         self.obs_agents = tuple(sorted(set(int(a) for a in obs_agents)))
         cfg = _lib.Config()
         cfg.width, cfg.height = layout.width, layout.height
-        self._keep = (np.ascontiguousarray(layout.wall_rows), np.ascontiguousarray(layout.food_rows),
-                      np.ascontiguousarray(layout.cap_rows), np.ascontiguousarray(layout.starts))
+        L = self.layouts
+        self._keep = (np.ascontiguousarray(np.stack([l.wall_rows for l in L])), np.ascontiguousarray(np.stack([l.food_rows for l in L])),
+                      np.ascontiguousarray(np.stack([l.cap_rows for l in L])), np.ascontiguousarray(np.stack([l.starts for l in L])))
+        if len(L) > 1:
+            if layout_index is None:
+                layout_index = np.arange(int(n_envs)) % len(L)
+            self.layout_index = np.ascontiguousarray(layout_index, np.int32)
+            assert self.layout_index.shape == (int(n_envs),)
+            cfg.n_layouts = len(L)
+            cfg.layout_index = self.layout_index.ctypes.data_as(C.POINTER(C.c_int32))
+        else:
+            self.layout_index = None
         cfg.wall_rows = self._keep[0].ctypes.data_as(C.POINTER(C.c_uint32))
         cfg.food_rows = self._keep[1].ctypes.data_as(C.POINTER(C.c_uint32))
         cfg.cap_rows = self._keep[2].ctypes.data_as(C.POINTER(C.c_uint32))
@@ -179,15 +197,16 @@ class PmxVecEnv:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.pmx_set_state(self.handle, first, count, arr, self._stream()), "pmx_set_state")
 
-    def maze_distances(self):
-        """distanceCalculator.computeDistances for this layout -> (cells [n,2] int8, dist [n,n] uint8) on the GPU."""
+    def maze_distances(self, layout=0):
+        """distanceCalculator.computeDistances for a layout -> (cells [n,2] int8, dist [n,n] uint8) on the GPU."""
         n = C.c_int32()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.pmx_maze_distances(self.handle, None, None, C.byref(n), self._stream()), "pmx_maze_distances")
+            _lib.check(self.lib.pmx_maze_distances_layout(self.handle, layout, None, None, C.byref(n), self._stream()),
+                       "pmx_maze_distances")
             cells = torch.empty((n.value, 2), dtype=torch.int8, device=self.device)
             dist = torch.empty((n.value, n.value), dtype=torch.uint8, device=self.device)
-            _lib.check(self.lib.pmx_maze_distances(self.handle, cells.data_ptr(), dist.data_ptr(), C.byref(n), self._stream()),
-                       "pmx_maze_distances")
+            _lib.check(self.lib.pmx_maze_distances_layout(self.handle, layout, cells.data_ptr(), dist.data_ptr(), C.byref(n),
+                                                          self._stream()), "pmx_maze_distances")
         return cells, dist
 
 

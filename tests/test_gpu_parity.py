@@ -383,3 +383,37 @@ def test_canonicalize_merge_golden():
             mr = torch.empty_like(o[0])
             assert lib.pmx_merge_obs(canon[0].data_ptr(), canon[2].data_ptr(), mr.data_ptr(), 1, H, W, code, st) == 0
             assert (mr.float().cpu().numpy() == d["merged_red"][j]).all()
+
+
+def test_per_env_layouts_vs_oracle():
+    """BASELINE config 5 in miniature: every env plays its own generated maze (20x20, 2 capsules each)."""
+    pmx = _pmx()
+    from pmx import maze_generator as MG
+    n_lay, N, T = 48, 768, 260
+    rows = [MG.generate_maze(seed).split("\n") for seed in range(1, n_lay + 1)]
+    lays = [pmx.Layout.from_text(r) for r in rows]
+    rng = np.random.RandomState(9)
+    index = rng.randint(0, n_lay, size=N).astype(np.int32)
+    env = pmx.PmxVecEnv(lays, N, length=120, auto_reset=True, obs_dtype="bfloat16", seed=5, layout_index=index)
+    orc = O.MultiBatchEnv(rows, index, length=120, auto_reset=True, seed=5)
+    obs0, legal0 = env.reset()
+    oobs = np.zeros((N, 4, 8, 20, 20), np.float32)
+    # initial observations: plane 0 must be each env's own walls
+    for e in range(0, N, 97):
+        lay = lays[index[e]]
+        w = np.array([[lay.is_wall(x, y) for x in range(20)] for y in range(20)], np.float32)
+        assert (obs0[e, 0, 0].float().cpu().numpy() == w).all()
+    for t in range(T):
+        a = rng.randint(0, 5, size=(N, 4)).astype(np.int8)
+        a[rng.rand(N, 4) < 0.5] = -2                     # random-legal moves keep the agents wandering
+        orc.tick(a, oobs)
+        obs, rew, done, info = env.step(torch.tensor(a).cuda())
+        assert rew.cpu().numpy().tobytes() == orc.reward.tobytes(), t
+        assert (done.cpu().numpy() == orc.done).all() and (info["legal_actions"].cpu().numpy() == orc.legal).all(), t
+        assert (info["agent"].cpu().numpy().astype(np.uint32) == orc.agent).all(), t
+        bad = np.nonzero((obs.float().cpu().numpy() != oobs).reshape(N, -1).any(1))[0]
+        assert len(bad) == 0, f"t={t}: obs differ for envs {bad[:8]} (layouts {index[bad[:8]]})"
+    cells, dist = env.maze_distances(layout=7)
+    oc, od = O.maze_distances(rows[7])
+    assert (cells.cpu().numpy() == oc).all() and (dist.cpu().numpy() == od).all()
+    env.close()
