@@ -30,6 +30,7 @@ WORKLOADS = {
     "small16384": ("smallCapture", 16384),   # BASELINE.json configs[2]: the layout the metric is quoted on
     "tiny4096": ("tinyCapture", 4096),       # configs[1]
     "blox4096": ("bloxCapture", 4096),       # the layout the reference actually trains on (20x20)
+    "mazes4096": ("mazeGenerator", 4096),    # configs[4] in miniature: per-env generated 20x20 mazes (256 distinct, cycled)
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy ceiling)
 ELEM = {"float32": 4, "bfloat16": 2, "uint8": 1}
@@ -131,8 +132,13 @@ def main():
     layname, n_envs = WORKLOADS[args.workload]
     if args.envs:
         n_envs = args.envs
-    lay = pmx.get_layout(layname)
-    H, W = lay.height, lay.width
+    if layname == "mazeGenerator":
+        from pmx import maze_generator
+        lay = [pmx.Layout.from_text(maze_generator.generate_maze(seed)) for seed in range(1, 257)]
+        H, W = lay[0].height, lay[0].width
+    else:
+        lay = pmx.get_layout(layname)
+        H, W = lay.height, lay.width
     length = 300
     dev = torch.device("cuda", local)
     env = pmx.PmxVecEnv(lay, n_envs, length=length, auto_reset=True, obs_dtype=args.obs, device=dev)
@@ -220,10 +226,10 @@ def main():
             "obs_checksum": checksum,
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(lay.text, length)
+            line["cpu_baseline"] = cpu_baseline(lay[0].text if isinstance(lay, list) else lay.text, length)
     env.close()
     ppo = None
-    if world == 1 and not args.no_ppo:
+    if world == 1 and not args.no_ppo and layname != "mazeGenerator":
         ppo = ppo_probe(layname, dev)
     if rank == 0:
         if ppo is not None:
