@@ -139,6 +139,7 @@ int launch_expand(pmx_env *env, void *obs, bool from_snapshots, int single_agent
     x.layout_idx = env->layout_idx_dev;
     x.obs = obs;
     x.N = env->cfg.n_envs;
+    x.lay_H = env->lay.H; x.lay_W = env->lay.W;
     x.single_agent = single_agent;
     if (single_agent >= 0) {
         x.n_emit = 1;

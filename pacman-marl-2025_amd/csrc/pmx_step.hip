@@ -10,6 +10,8 @@
 //                      This kernel moves >95 % of the bytes of the tick and is the HBM-roofline kernel.
 // The split keeps the divergent integer rule logic at 64 envs per wave while the byte-heavy expansion gets
 // N*4 wavefronts of perfectly coalesced stores regardless of N.
+#include <cstdlib>
+
 #include "pmx_device.h"
 
 #define PMX_MAX_H_LDS 32   // per-lane wall columns (multi-layout handles) start after room for 32 food rows
@@ -532,7 +534,7 @@ __device__ __forceinline__ void stream_or_row(uint32_t *T, uint32_t off, uint32_
 //      32-bit word), expands it and issues one non-temporal dwordx4 store: the wave writes 1 KiB of consecutive
 //      addresses per instruction.  LDS operations of one wavefront execute in order, so no barrier is needed.
 // ---------------------------------------------------------------------------------------------------------------
-template <int DT>
+template <int DT, bool NT>
 __global__ __launch_bounds__(PMX_BLOCK) void pmx_expand_kernel(PmxExpandParams p)
 {
     constexpr int VEC = ObsVec<DT>::VEC;
@@ -604,9 +606,12 @@ __global__ __launch_bounds__(PMX_BLOCK) void pmx_expand_kernel(PmxExpandParams p
         uint4 v = pack_obs<DT>(bits);
         const uint32_t d = (uint32_t)(fself - (int)e0);
         if (d < (uint32_t)VEC) patch_self<DT>(v, (int)d, carry);
-        // streaming stores: the planes are consumed by a later kernel, not re-read here (merged into one dwordx4 nt)
-        __builtin_nontemporal_store(v.x, &out[k].x); __builtin_nontemporal_store(v.y, &out[k].y);
-        __builtin_nontemporal_store(v.z, &out[k].z); __builtin_nontemporal_store(v.w, &out[k].w);
+        if (NT) {   // streaming stores (merged into one dwordx4 nt): used when the planes exceed the Infinity Cache
+            __builtin_nontemporal_store(v.x, &out[k].x); __builtin_nontemporal_store(v.y, &out[k].y);
+            __builtin_nontemporal_store(v.z, &out[k].z); __builtin_nontemporal_store(v.w, &out[k].w);
+        } else {
+            out[k] = v;
+        }
     }
 }
 
@@ -649,10 +654,21 @@ extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, int dtype, hip
 {
     const long waves = (long)p->N * p->n_emit;
     const unsigned blocks = (unsigned)((waves + 3) / 4);
+    // Store policy by footprint: planes that fit the 256 MiB Infinity Cache (with room for the consumer's reads) are
+    // written with ordinary stores, larger ones with non-temporal stores (measured in one process, tools/ab_expand.py).
+    const size_t elem = dtype == 0 ? 4 : (dtype == 1 ? 2 : 1);
+    const size_t bytes = (size_t)waves * 8 * p->lay_H * p->lay_W * elem;
+    bool nt = bytes > ((size_t)384 << 20);
+    if (const char *o = getenv("PMX_EXPAND_NT")) nt = atoi(o) != 0;      // experiment override
+#define PMX_EXPAND_LAUNCH(DT)                                                                              \
+    do {                                                                                                   \
+        if (nt) hipLaunchKernelGGL((pmx_expand_kernel<DT, true>), dim3(blocks), dim3(PMX_BLOCK), 0, st, *p); \
+        else hipLaunchKernelGGL((pmx_expand_kernel<DT, false>), dim3(blocks), dim3(PMX_BLOCK), 0, st, *p);   \
+    } while (0)
     switch (dtype) {
-    case 0: hipLaunchKernelGGL(pmx_expand_kernel<0>, dim3(blocks), dim3(PMX_BLOCK), 0, st, *p); break;
-    case 1: hipLaunchKernelGGL(pmx_expand_kernel<1>, dim3(blocks), dim3(PMX_BLOCK), 0, st, *p); break;
-    default: hipLaunchKernelGGL(pmx_expand_kernel<2>, dim3(blocks), dim3(PMX_BLOCK), 0, st, *p); break;
+    case 0: PMX_EXPAND_LAUNCH(0); break;
+    case 1: PMX_EXPAND_LAUNCH(1); break;
+    default: PMX_EXPAND_LAUNCH(2); break;
     }
     return hipGetLastError();
 }
