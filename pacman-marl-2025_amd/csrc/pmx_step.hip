@@ -654,11 +654,15 @@ extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, int dtype, hip
 {
     const long waves = (long)p->N * p->n_emit;
     const unsigned blocks = (unsigned)((waves + 3) / 4);
-    // Store policy by footprint: planes that fit the 256 MiB Infinity Cache (with room for the consumer's reads) are
-    // written with ordinary stores, larger ones with non-temporal stores (measured in one process, tools/ab_expand.py).
+    // Store policy, measured in one process with tools/ab_expand.py (us per launch, ordinary / non-temporal stores):
+    //   f32   323 MB 56.7/64.7   646 MB 117/126    969 MB 189/186   1.29 GB 262/236
+    //   bf16  161 MB 31.6/35.9   323 MB 61.1/66.7  646 MB 172/124
+    //   u8     80 MB 29.6/28.5   323 MB 111/102
+    // Ordinary stores win while the 256 MiB Infinity Cache can absorb a good part of the planes; beyond that, and for
+    // the short uint8 blocks, streaming stores win.
     const size_t elem = dtype == 0 ? 4 : (dtype == 1 ? 2 : 1);
     const size_t bytes = (size_t)waves * 8 * p->lay_H * p->lay_W * elem;
-    bool nt = bytes > ((size_t)384 << 20);
+    bool nt = elem == 1 || (elem == 2 && bytes > ((size_t)512 << 20)) || (elem == 4 && bytes > ((size_t)900 << 20));
     if (const char *o = getenv("PMX_EXPAND_NT")) nt = atoi(o) != 0;      // experiment override
 #define PMX_EXPAND_LAUNCH(DT)                                                                              \
     do {                                                                                                   \
