@@ -19,7 +19,8 @@
 namespace {
 
 struct Env {
-    int x[4], y[4], dir[4], pac[4], scared[4], carry[4], ret[4];
+    uint32_t xy[4];        // x | y << 8: one compare tests "same cell" (capture.py:682,708 collisions at tolerance 0.7)
+    int dir[4], pac[4], scared[4], carry[4], ret[4];
     uint32_t capw[2];
     int score, steps;
     uint32_t ticks;        // never reset
@@ -40,11 +41,12 @@ struct Ctx {
     int W, H, half, n_dump;
     int legal_reward, defence_reward;
     uint32_t rng_key;     // seed ^ env * 0x9E3779B1 (the per-env part of the random-legal key)
+    uint32_t start_xy[4]; // start cells, packed like Env::xy
 };
 
 __device__ __forceinline__ uint32_t pack_a(const Env &e, int i)
 {
-    return (uint32_t)e.x[i] | ((uint32_t)e.y[i] << 8) | ((uint32_t)e.dir[i] << 16) | ((uint32_t)e.pac[i] << 24);
+    return e.xy[i] | ((uint32_t)e.dir[i] << 16) | ((uint32_t)e.pac[i] << 24);
 }
 __device__ __forceinline__ uint32_t pack_b(const Env &e, int i)
 {
@@ -52,7 +54,7 @@ __device__ __forceinline__ uint32_t pack_b(const Env &e, int i)
 }
 __device__ __forceinline__ void unpack_a(Env &e, int i, uint32_t w)
 {
-    e.x[i] = w & 0xFF; e.y[i] = (w >> 8) & 0xFF; e.dir[i] = (w >> 16) & 0xFF; e.pac[i] = (w >> 24) & 1;
+    e.xy[i] = w & 0xFFFFu; e.dir[i] = (w >> 16) & 0xFF; e.pac[i] = (w >> 24) & 1;
 }
 __device__ __forceinline__ void unpack_b(Env &e, int i, uint32_t w)
 {
@@ -67,9 +69,9 @@ __device__ __forceinline__ int legal_mask(const uint32_t *wl, int wls, int x, in
                  (((r0 >> (x - 1)) & 1u) << 3) | (((r0 >> x) & 1u) << 4));
 }
 
-__device__ __forceinline__ int cap_find(const Env &e, int x, int y)
+__device__ __forceinline__ int cap_find(const Env &e, uint32_t key)
 {
-    uint32_t key = (uint32_t)x | ((uint32_t)y << 8);
+    if ((e.capw[0] & e.capw[1]) == 0xFFFFFFFFu) return -1;      // no capsule left (the common case)
     if ((e.capw[0] & 0xFFFFu) == key) return 0;
     if ((e.capw[0] >> 16) == key) return 1;
     if ((e.capw[1] & 0xFFFFu) == key) return 2;
@@ -84,13 +86,14 @@ __device__ __forceinline__ void cap_remove(Env &e, int slot)
 
 __device__ __forceinline__ void send_home(Env &e, const Ctx &c, int i)
 {   // capture.py:691-693 / 699-701 / 717-719 / 725-727
-    e.pac[i] = 0; e.x[i] = c.L->startx[i]; e.y[i] = c.L->starty[i]; e.dir[i] = 4; e.scared[i] = 0;
+    e.pac[i] = 0; e.xy[i] = c.start_xy[i]; e.dir[i] = 4; e.scared[i] = 0;
 }
 
 // capture.py:569-668 dumpFoodFromDeath.  The reference's FIFO BFS visits offsets in a board-independent order;
 // c.dump holds that order (generated on the host by running the same BFS), so the walk is a linear scan.
-__device__ __forceinline__ void dump_food(Env &e, const Ctx &c, int who_x, int who_y, int num, int &d_red, int &d_blue)
+__device__ __forceinline__ void dump_food(Env &e, const Ctx &c, uint32_t who_xy, int num, int &d_red, int &d_blue)
 {
+    const int who_x = who_xy & 0xFF, who_y = who_xy >> 8;
     const int side_red = 2 * who_x < c.W;
     for (int k = 0; k < c.n_dump && num > 0; ++k) {
         int X = who_x + c.dump[2 * k], Y = who_y + c.dump[2 * k + 1];
@@ -99,11 +102,9 @@ __device__ __forceinline__ void dump_food(Env &e, const Ctx &c, int who_x, int w
         uint32_t row = c.fd[Y * PMX_RULE_BLOCK];
         if ((row >> X) & 1u) continue;                                    // :614
         if ((2 * X < c.W) != side_red) continue;                          // :618
-        if (cap_find(e, X, Y) >= 0) continue;                             // :621
-        bool occ = false;                                                 // :625-627
-#pragma unroll
-        for (int i = 0; i < 4; ++i) occ |= (e.x[i] == X && e.y[i] == Y);
-        if (occ) continue;
+        const uint32_t key = (uint32_t)X | ((uint32_t)Y << 8);
+        if (cap_find(e, key) >= 0) continue;                              // :621
+        if (e.xy[0] == key || e.xy[1] == key || e.xy[2] == key || e.xy[3] == key) continue;   // :625-627
         c.fd[Y * PMX_RULE_BLOCK] = row | (1u << X);
         --num;
         if (X < c.half) ++d_red; else ++d_blue;
@@ -113,7 +114,7 @@ __device__ __forceinline__ void dump_food(Env &e, const Ctx &c, int who_x, int w
 template <int WHO>
 __device__ __forceinline__ void kill_dump(Env &e, const Ctx &c, int &d_red, int &d_blue)
 {
-    if (e.pac[WHO] && e.carry[WHO] > 0) dump_food(e, c, e.x[WHO], e.y[WHO], e.carry[WHO], d_red, d_blue);
+    if (e.pac[WHO] && e.carry[WHO] > 0) dump_food(e, c, e.xy[WHO], e.carry[WHO], d_red, d_blue);
     if (e.pac[WHO]) e.carry[WHO] = 0;   // (a non-Pacman here is the reference's "seriously wrong" raise: unreachable)
 }
 
@@ -121,15 +122,16 @@ __device__ __forceinline__ void kill_dump(Env &e, const Ctx &c, int &d_red, int 
 template <bool RED>
 __device__ __forceinline__ void consume(Env &e, const Ctx &c, int px, int py, int &d_red, int &d_blue)
 {
+    const uint32_t key = (uint32_t)px | ((uint32_t)py << 8);
     uint32_t row = c.fd[py * PMX_RULE_BLOCK];
     if ((row >> px) & 1u) {
         constexpr int T1 = RED ? 0 : 1, T2 = T1 + 2;                      // :533-537 team order
-        if (e.x[T1] == px && e.y[T1] == py) e.carry[T1] += 1;
-        else if (e.x[T2] == px && e.y[T2] == py) e.carry[T2] += 1;
+        if (e.xy[T1] == key) e.carry[T1] += 1;
+        else if (e.xy[T2] == key) e.carry[T2] += 1;
         c.fd[py * PMX_RULE_BLOCK] = row & ~(1u << px);
         if (px < c.half) --d_red; else --d_blue;
     }
-    int slot = cap_find(e, px, py);
+    int slot = cap_find(e, key);
     if (slot >= 0) {
         bool mine = RED ? (2 * px > c.W) : (2 * px <= c.W);               // halfList, capture.py:344-350
         if (mine) {
@@ -166,14 +168,14 @@ __device__ __forceinline__ int substep(Env &e, const Ctx &c, int action, bool &r
     constexpr bool RED = (I % 2) == 0;
     constexpr int O1 = RED ? 1 : 0, O2 = O1 + 2;
     // ---- applyAction capture.py:468-517
-    const int legal = legal_mask(c.wl, c.wls, e.x[I], e.y[I]);
+    int px = e.xy[I] & 0xFF, py = e.xy[I] >> 8;
+    const int legal = legal_mask(c.wl, c.wls, px, py);
     if (action == -2) action = random_legal(legal, c.rng_key, e.ticks, I);
     req_legal = (action >= 0) && (action <= 4) && ((legal >> (action & 7)) & 1);
     if (!req_legal) action = 4;                                           // :473-474
-    const int dx = (action == 1) - (action == 3), dy = (action == 0) - (action == 2);
-    e.x[I] += dx; e.y[I] += dy;
+    px += (action == 1) - (action == 3); py += (action == 0) - (action == 2);
+    e.xy[I] = (uint32_t)px | ((uint32_t)py << 8);
     if (action != 4) e.dir[I] = action;                                   // game.py:115-118
-    const int px = e.x[I], py = e.y[I];
     e.pac[I] = (int)(RED != (2 * px < c.W));                              // :492
     int eater_pac = e.pac[I];
     int sc = 0;
@@ -184,24 +186,28 @@ __device__ __forceinline__ int substep(Env &e, const Ctx &c, int action, bool &r
         eater_pac = e.pac[3];                                             // :505 leaves agentState bound to agent 3
     }
     if (eater_pac) consume<RED>(e, c, px, py, d_red, d_blue);            // :514-515
-    // ---- checkDeath capture.py:670-728; the isPacman branch is chosen once, positions are re-read per opponent
-    if (e.pac[I]) {
-        if (!e.pac[O1] && e.x[O1] == e.x[I] && e.y[O1] == e.y[I]) {
-            if (e.scared[O1] <= 0) { kill_dump<I>(e, c, d_red, d_blue); send_home(e, c, I); }
-            else send_home(e, c, O1);
-        }
-        if (!e.pac[O2] && e.x[O2] == e.x[I] && e.y[O2] == e.y[I]) {
-            if (e.scared[O2] <= 0) { kill_dump<I>(e, c, d_red, d_blue); send_home(e, c, I); }
-            else send_home(e, c, O2);
-        }
-    } else {
-        if (e.pac[O1] && e.x[O1] == e.x[I] && e.y[O1] == e.y[I]) {
-            if (e.scared[I] <= 0) { kill_dump<O1>(e, c, d_red, d_blue); send_home(e, c, O1); }
-            else send_home(e, c, I);
-        }
-        if (e.pac[O2] && e.x[O2] == e.x[I] && e.y[O2] == e.y[I]) {
-            if (e.scared[I] <= 0) { kill_dump<O2>(e, c, d_red, d_blue); send_home(e, c, O2); }
-            else send_home(e, c, I);
+    // ---- checkDeath capture.py:670-728.  Nothing happens unless an opponent stands on the mover's cell, so the common
+    // case is two compares; the sequential logic (the isPacman branch is chosen once, positions are re-read per
+    // opponent because the mover may have been sent home in between) runs only on a collision.
+    if (e.xy[O1] == e.xy[I] || e.xy[O2] == e.xy[I]) {
+        if (e.pac[I]) {
+            if (!e.pac[O1] && e.xy[O1] == e.xy[I]) {
+                if (e.scared[O1] <= 0) { kill_dump<I>(e, c, d_red, d_blue); send_home(e, c, I); }
+                else send_home(e, c, O1);
+            }
+            if (!e.pac[O2] && e.xy[O2] == e.xy[I]) {
+                if (e.scared[O2] <= 0) { kill_dump<I>(e, c, d_red, d_blue); send_home(e, c, I); }
+                else send_home(e, c, O2);
+            }
+        } else {
+            if (e.pac[O1] && e.xy[O1] == e.xy[I]) {
+                if (e.scared[I] <= 0) { kill_dump<O1>(e, c, d_red, d_blue); send_home(e, c, O1); }
+                else send_home(e, c, I);
+            }
+            if (e.pac[O2] && e.xy[O2] == e.xy[I]) {
+                if (e.scared[I] <= 0) { kill_dump<O2>(e, c, d_red, d_blue); send_home(e, c, O2); }
+                else send_home(e, c, I);
+            }
         }
     }
     e.scared[I] = e.scared[I] > 1 ? e.scared[I] - 1 : 0;                  // capture.py:562-567, mover only
@@ -229,13 +235,13 @@ __device__ __forceinline__ void tick_substep(Env &e, Acc &a, const Ctx &c, int a
         if (d_red < 0) r += 0.1;
     }
     if (c.defence_reward) {
-        if (pac1 && !e.pac[O1] && e.x[O1] == c.L->startx[O1] && e.y[O1] == c.L->starty[O1]) r += 0.25;
-        if (pac2 && !e.pac[O2] && e.x[O2] == c.L->startx[O2] && e.y[O2] == c.L->starty[O2]) r += 0.25;
+        if (pac1 && !e.pac[O1] && e.xy[O1] == c.start_xy[O1]) r += 0.25;
+        if (pac2 && !e.pac[O2] && e.xy[O2] == c.start_xy[O2]) r += 0.25;
     }
     if (c.legal_reward && req_legal) r += 0.01;                           // :254-257
     if (RED) { a.red_r = r; a.red_sc += sc; } else { a.blue_r = r; a.blue_sc -= sc; }
     a.sc_total += sc;                                                     // :153-162
-    e.self_after[I] = (uint32_t)e.x[I] | ((uint32_t)e.y[I] << 8) | ((uint32_t)e.carry[I] << 16);
+    e.self_after[I] = e.xy[I] | ((uint32_t)e.carry[I] << 16);
 }
 
 __device__ __forceinline__ void load_env(Env &e, const Ctx &c, const uint32_t *st, int N, int env)
@@ -280,7 +286,7 @@ __device__ __forceinline__ void init_env(Env &e, const Ctx &c)
     for (int y = 0; y < c.H; ++y) c.fd[y * PMX_RULE_BLOCK] = c.L->food0[y];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        e.x[i] = c.L->startx[i]; e.y[i] = c.L->starty[i]; e.dir[i] = 4;
+        e.xy[i] = c.start_xy[i]; e.dir[i] = 4;
         e.pac[i] = 0; e.scared[i] = 0; e.carry[i] = 0; e.ret[i] = 0;
     }
     e.capw[0] = c.L->capw0[0]; e.capw[1] = c.L->capw0[1];
@@ -324,7 +330,7 @@ __device__ __forceinline__ void tick_finish(Env &e, Acc &a, const Ctx &c, const 
     if (p.legal) {
         uint32_t m = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) m |= (uint32_t)legal_mask(c.wl, c.wls, e.x[i], e.y[i]) << (8 * i);
+        for (int i = 0; i < 4; ++i) m |= (uint32_t)legal_mask(c.wl, c.wls, (int)(e.xy[i] & 0xFF), (int)(e.xy[i] >> 8)) << (8 * i);
         reinterpret_cast<uint32_t *>(p.legal)[env] = m;
     }
 }
@@ -341,6 +347,8 @@ __device__ __forceinline__ Ctx make_ctx(const PmxTickParams &p, uint32_t *lds)
     c.wl = multi ? lds + 32 + PMX_MAX_H_LDS * PMX_RULE_BLOCK + threadIdx.x : lds;
     c.wls = multi ? PMX_RULE_BLOCK : 1;
     c.fd = lds + 32 + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c.start_xy[i] = (uint32_t)c.L->startx[i] | ((uint32_t)c.L->starty[i] << 8);
     c.rng_key = p.seed ^ ((uint32_t)(blockIdx.x * PMX_RULE_BLOCK + threadIdx.x) * 0x9E3779B1u);
     if (threadIdx.x < 32) lds[threadIdx.x] = threadIdx.x < (unsigned)c.H ? p.lay->walls[threadIdx.x] : 0xFFFFFFFFu;
     if (multi) {   // per-env layouts: every lane keeps its own wall column next to its food column
@@ -394,7 +402,7 @@ __device__ __forceinline__ void rule_agent_body(const PmxTickParams &p, uint32_t
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)   // sub-steps not yet taken report the current state
-        e.self_after[i] = (uint32_t)e.x[i] | ((uint32_t)e.y[i] << 8) | ((uint32_t)e.carry[i] << 16);
+        e.self_after[i] = e.xy[i] | ((uint32_t)e.carry[i] << 16);
     tick_substep<I>(e, a, c, (int)p.actions[env]);
     if (p.agent_out) p.agent_out[4 * (size_t)env + I] = e.self_after[I];
     if (I == 3) {
@@ -464,7 +472,7 @@ extern "C" __global__ __launch_bounds__(PMX_RULE_BLOCK) void pmx_reset_kernel(Pm
     if (p.legal) {
         uint32_t m = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) m |= (uint32_t)legal_mask(c.wl, c.wls, e.x[i], e.y[i]) << (8 * i);
+        for (int i = 0; i < 4; ++i) m |= (uint32_t)legal_mask(c.wl, c.wls, (int)(e.xy[i] & 0xFF), (int)(e.xy[i] >> 8)) << (8 * i);
         reinterpret_cast<uint32_t *>(p.legal)[env] = m;
     }
 }

@@ -143,7 +143,11 @@ def _add_pacman_stuff(maze, max_food=60, max_capsules=4, toskip=0):   # :194-251
     maze.grid[1][maze.c - 2] = "4"
     maze.grid[2][maze.c - 2] = "2"
     total_capsules = 0
+    draws = 0
     while total_capsules < max_capsules:
+        draws += 1
+        if draws > 200000:   # the reference loops forever when no cell qualifies (only possible for non-reference sizes)
+            raise ValueError("maze size leaves no legal capsule cell")
         row = rng.randint(1, maze.r - 1)
         col = rng.randint(1 + toskip, (maze.c // 2) - 2)
         if (row > maze.r - 6) and (col < 6):
@@ -154,7 +158,11 @@ def _add_pacman_stuff(maze, max_food=60, max_capsules=4, toskip=0):   # :194-251
             maze.grid[row][col] = C
             maze.grid[row][maze.c - col - 1] = C
             total_capsules += 2
+    draws = 0
     while total_food < max_food:
+        draws += 1
+        if draws > 2000000:
+            raise ValueError("maze size leaves too few legal food cells")
         row = rng.randint(1, maze.r - 1)
         col = rng.randint(1 + toskip, (maze.c // 2) - 1)
         if (row > maze.r - 6) and (col < 6):

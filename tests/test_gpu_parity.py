@@ -417,3 +417,34 @@ def test_per_env_layouts_vs_oracle():
     oc, od = O.maze_distances(rows[7])
     assert (cells.cpu().numpy() == oc).all() and (dist.cpu().numpy() == od).all()
     env.close()
+
+
+_TINY_BOARD = ["%%%%%%%%", "%1 .. 2%", "%  ..  %", "%3 .. 4%", "%%%%%%%%"]
+
+
+@pytest.mark.parametrize("rows_cols,dtype,N", [((14, 15), "uint8", 333), (None, "float32", 130), ((30, 15), "bfloat16", 257)])
+def test_other_board_sizes_vs_oracle(rows_cols, dtype, N):
+    """Boards at the edges of the supported range (32 wide: every shift count of the bit rows is exercised; 8 x 5;
+    32 x 32) with batch sizes that are not multiples of the wave / block size."""
+    pmx = _pmx()
+    from pmx import maze_generator as MG
+    rows = _TINY_BOARD if rows_cols is None else MG.generate_maze(11, rows=rows_cols[0], cols=rows_cols[1]).split("\n")
+    lay = pmx.Layout.from_text(rows)
+    H, W = lay.height, lay.width
+    env = pmx.PmxVecEnv(lay, N, length=60, auto_reset=True, obs_dtype=dtype, seed=1)
+    orc = O.BatchEnv(rows, N, length=60, auto_reset=True, seed=1)
+    env.reset()
+    rng = np.random.RandomState(2)
+    oobs = np.zeros((N, 4, 8, H, W), np.float32)
+    for t in range(150):
+        a = rng.randint(0, 5, size=(N, 4)).astype(np.int8)
+        a[rng.rand(N, 4) < 0.6] = -2
+        orc.tick(a, oobs)
+        obs, rew, done, info = env.step(torch.tensor(a).cuda())
+        assert rew.cpu().numpy().tobytes() == orc.reward.tobytes(), t
+        assert (done.cpu().numpy() == orc.done).all() and (info["legal_actions"].cpu().numpy() == orc.legal).all(), t
+        assert (obs.float().cpu().numpy() == oobs).all(), t
+    cells, dist = env.maze_distances()
+    oc, od = O.maze_distances(rows)
+    assert (cells.cpu().numpy() == oc).all() and (dist.cpu().numpy() == od).all()
+    env.close()
