@@ -238,6 +238,36 @@ class VecMAPPOTrainer:
         self.gen.set_state(ck["gen"].cpu()); self.np_rng.set_state(ck["np_rng"])
 
 
+def evaluate_vs_bots(model, num_episodes=20, layout_file="bloxCapture", teams=("baselineTeam", "randomTeam"), length=300,
+                     device="cuda:0"):
+    """evaluate_vs_bots (pacman_mappo_resnet.py:293-337): a fresh env per episode against host CaptureAgent bots (red),
+    the learner plays blue with argmax actions; returns (mean return, std, win rate), a win being final score < 0.
+    The reference cycles through its A*/approx-Q/baseline/MCTS teams; here through the team files this build ships."""
+    from .gym_env import gymPacMan_parallel_env
+    was_training = model.training
+    model.eval()
+    returns, wins = [], 0
+    learner_ids = [1, 3]
+    for ep in range(num_episodes):
+        env = gymPacMan_parallel_env(layout_file=layout_file, display=False, reward_forLegalAction=True, defenceReward=True,
+                                     length=length, enemieName=teams[ep % len(teams)], self_play=False, device=device)
+        obs_dict, _ = env.reset()
+        ep_ret, done = 0.0, False
+        while not done:
+            lo = torch.stack([obs_dict[env.agents[i]].float() for i in learner_ids])
+            with torch.no_grad():
+                acts = model.get_deterministic_action(lo.to(next(model.parameters()).device)).cpu()
+            obs_dict, rewards, dones, _ = env.step({env.agents[a]: int(acts[k]) for k, a in enumerate(learner_ids)})
+            ep_ret += sum(rewards[env.agents[i]] for i in learner_ids)
+            done = any(dones.values())
+        returns.append(ep_ret)
+        wins += int(env.game.state.data.score < 0)
+        env.close()
+    if was_training:
+        model.train()
+    return float(np.mean(returns)), float(np.std(returns)), wins / num_episodes
+
+
 class _NullCtx:
     def __enter__(self):
         return self

@@ -123,3 +123,11 @@ def test_graph_captured_step_equals_eager_step():
         assert torch.allclose(sa["grad_norm"], sb["grad_norm"], rtol=1e-3), k
     assert torch.allclose(la.bucket.data, lb.bucket.data, rtol=1e-3, atol=2e-5)
     assert torch.allclose(la.ema, lb.ema, rtol=1e-3, atol=2e-5)
+
+
+def test_evaluate_vs_bots_runs():
+    from pmx import mappo, trainer
+    torch.manual_seed(0)
+    model = mappo.MAPPOAgent((8, 7, 20), 5, 2).cuda()
+    mean, std, wr = trainer.evaluate_vs_bots(model, num_episodes=2, layout_file="tinyCapture", teams=("randomTeam", "baselineTeam"), length=30)
+    assert np.isfinite(mean) and np.isfinite(std) and 0.0 <= wr <= 1.0

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""MAPPO training on the vectorised env, one process per GPU.
+
+    python tools/train.py --envs 16384 --horizon 32 --updates 100
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/train.py --envs 8192 ...
+
+Every rank owns its env shard, rollout buffers, GAE and minibatch sampling; the only exchange is one flat-gradient
+all-reduce per optimizer step over RCCL (pmx.mappo.PPOLearner)."""
+import argparse, json, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--layout", default="smallCapture")
+ap.add_argument("--envs", type=int, default=16384, help="envs per GPU")
+ap.add_argument("--horizon", type=int, default=32)
+ap.add_argument("--minibatch", type=int, default=8192, help="samples per optimizer step per GPU (reference: 512)")
+ap.add_argument("--epochs", type=int, default=3)
+ap.add_argument("--updates", type=int, default=10)
+ap.add_argument("--total-updates", type=int, default=2000)
+ap.add_argument("--opponent", default="curriculum", choices=["random", "self", "pool", "curriculum"])
+ap.add_argument("--obs", default="bfloat16")
+ap.add_argument("--eval-every", type=int, default=0)
+ap.add_argument("--save", default="")
+ap.add_argument("--seed", type=int, default=0)
+args = ap.parse_args()
+
+rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+torch.cuda.set_device(local)
+pg = None
+if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+from pmx import trainer
+
+tr = trainer.VecMAPPOTrainer(args.layout, args.envs, horizon=args.horizon, minibatch=args.minibatch, epochs=args.epochs,
+                             obs_dtype=args.obs, device=f"cuda:{local}", seed=args.seed, rank=rank, world_size=world,
+                             total_updates=args.total_updates, opponent=args.opponent)
+for u in range(args.updates):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    st = tr.train_update()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    if rank == 0:
+        f = lambda k: float(st[k]) if k in st else None
+        print(json.dumps(dict(update=u, opponent=st["opponent"], red=st["play_as_red"], sec=round(dt, 3),
+                              env_steps_per_s=round(world * tr.N * tr.T / dt), episodes=int(st["episodes"]),
+                              win_rate=(float(st["wins"]) / max(int(st["episodes"]), 1)),
+                              reward=float(st["rollout_reward"]) / max(tr.N, 1), pg=f("pg"), vl=f("vl"), entropy=f("entropy"),
+                              clip_frac=f("clip_frac"), grad_norm=f("grad_norm"), steps=st["optimizer_steps"])), flush=True)
+        if args.eval_every and u and u % args.eval_every == 0:
+            tr.model.load_state_dict(tr.model.state_dict())
+            print(json.dumps(dict(update=u, eval=trainer.evaluate_vs_bots(tr.model, 4, args.layout, device=f"cuda:{local}"))), flush=True)
+if rank == 0 and args.save:
+    tr.save_ema(args.save)
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
