@@ -1,6 +1,9 @@
 // pmx_train.hip -- the non-tick kernels of the path (gfx950): GAE reverse scan, maze distances, observation
 // post-processing.  C-ABI entry points for pmx_gae / pmx_canonicalize_obs / pmx_merge_obs live here too.
+#include <algorithm>
 #include <cstdio>
+
+#include <hip/hip_bf16.h>
 
 #include "../../include/pmx.h"
 #include "pmx_device.h"
@@ -224,5 +227,153 @@ extern "C" int pmx_merge_obs(const void *a_dev, const void *b_dev, void *out_dev
     case PMX_OBS_U8: hipLaunchKernelGGL(pmx_merge_kernel<uint8_t>, grid, block, 0, st, (const uint8_t *)a_dev, (const uint8_t *)b_dev, (uint8_t *)out_dev, total, H * W); break;
     default: return PMX_ERR_INVALID;
     }
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused residual-add + LayerNorm over a SMALL feature dimension (the critic's d_model = 32,
+// pacman_mappo_resnet.py:138-141 post-LN encoder layers): y = LayerNorm(x + a) * w + b.  One LANE per token row, the
+// 32 features of the row in registers, 16-byte loads/stores; float32 statistics whatever the IO type.  torch's native
+// LayerNorm spends a workgroup per row (1.7 ms for the [154*4096, 32] token matrix); the reduce + elementwise
+// formulation needs ~6 kernels forward and ~12 backward.  The backward kernel recomputes x + a, produces the (shared)
+// input gradient and accumulates the weight / bias gradients per lane over a grid-stride loop, reduces them across
+// the wavefront with shuffles and adds 64 floats per wave to the global accumulators.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T> struct LnIO;
+template <> struct LnIO<float> {
+    static __device__ __forceinline__ void load(const float *p, float *v) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { float4 t = reinterpret_cast<const float4 *>(p)[k]; v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w; }
+    }
+    static __device__ __forceinline__ void store(float *p, const float *v) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) reinterpret_cast<float4 *>(p)[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    }
+};
+template <> struct LnIO<__hip_bfloat16> {
+    static __device__ __forceinline__ void load(const __hip_bfloat16 *p, float *v) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint4 t = reinterpret_cast<const uint4 *>(p)[k];
+            const uint32_t w[4] = { t.x, t.y, t.z, t.w };
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[8 * k + 2 * j] = __uint_as_float(w[j] << 16); v[8 * k + 2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u); }
+        }
+    }
+    static __device__ __forceinline__ void store(__hip_bfloat16 *p, const float *v) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const __hip_bfloat16 lo = __float2bfloat16(v[8 * k + 2 * j]), hi = __float2bfloat16(v[8 * k + 2 * j + 1]);
+                w[j] = (uint32_t)(*reinterpret_cast<const uint16_t *>(&lo)) | ((uint32_t)(*reinterpret_cast<const uint16_t *>(&hi)) << 16);
+            }
+            reinterpret_cast<uint4 *>(p)[k] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void pmx_ln32_fwd_kernel(const T *__restrict__ x, const T *__restrict__ a, const float *__restrict__ w,
+                                                           const float *__restrict__ b, T *__restrict__ y, float *__restrict__ mean_out,
+                                                           float *__restrict__ rstd_out, long rows, float eps)
+{
+    constexpr int D = 32;
+    float wv[D], bv[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) { wv[j] = w[j]; bv[j] = b[j]; }
+    for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) {
+        float z[D], t[D];
+        LnIO<T>::load(x + r * D, z);
+        LnIO<T>::load(a + r * D, t);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < D; ++j) { z[j] += t[j]; s += z[j]; }
+        const float mean = s * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < D; ++j) { const float c = z[j] - mean; q += c * c; }
+        const float rstd = rsqrtf(q * (1.0f / D) + eps);
+#pragma unroll
+        for (int j = 0; j < D; ++j) t[j] = (z[j] - mean) * rstd * wv[j] + bv[j];
+        LnIO<T>::store(y + r * D, t);
+        mean_out[r] = mean; rstd_out[r] = rstd;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pmx_ln32_bwd_kernel(const T *__restrict__ x, const T *__restrict__ a, const T *__restrict__ dy,
+                                                           const float *__restrict__ w, const float *__restrict__ mean_in,
+                                                           const float *__restrict__ rstd_in, T *__restrict__ dz, float *__restrict__ dw,
+                                                           float *__restrict__ db, long rows)
+{
+    constexpr int D = 32;
+    float wv[D], gw[D], gb[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) { wv[j] = w[j]; gw[j] = 0.f; gb[j] = 0.f; }
+    for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) {
+        float z[D], t[D], g[D];
+        LnIO<T>::load(x + r * D, z);
+        LnIO<T>::load(a + r * D, t);
+        LnIO<T>::load(dy + r * D, g);
+        const float mean = mean_in[r], rstd = rstd_in[r];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const float xh = (z[j] + t[j] - mean) * rstd;
+            gw[j] += g[j] * xh; gb[j] += g[j];
+            const float gg = g[j] * wv[j];
+            c1 += gg; c2 += gg * xh;
+            z[j] = xh; g[j] = gg;
+        }
+        c1 *= (1.0f / D); c2 *= (1.0f / D);
+#pragma unroll
+        for (int j = 0; j < D; ++j) t[j] = rstd * (g[j] - c1 - z[j] * c2);
+        LnIO<T>::store(dz + r * D, t);
+    }
+    // wavefront reduction of the 64 accumulators, then one atomic per value per wave
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { gw[j] += __shfl_xor(gw[j], o); gb[j] += __shfl_xor(gb[j], o); }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) { atomicAdd(&dw[j], gw[j]); atomicAdd(&db[j], gb[j]); }
+    }
+}
+
+// dtype: 0 float32, 1 bfloat16.  Feature dimension fixed at 32.
+extern "C" int pmx_ln32_forward(const void *x, const void *a, const float *w, const float *b, void *y, float *mean, float *rstd,
+                                int64_t rows, float eps, int32_t dtype, void *stream)
+{
+    if (!x || !a || !w || !b || !y || !mean || !rstd || rows < 0) return PMX_ERR_INVALID;
+    if (rows == 0) return PMX_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const unsigned grid = (unsigned)std::min<int64_t>((rows + 255) / 256, 4096);
+    if (dtype == 0)
+        hipLaunchKernelGGL(pmx_ln32_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, (const float *)a, w, b, (float *)y, mean, rstd, (long)rows, eps);
+    else
+        hipLaunchKernelGGL(pmx_ln32_fwd_kernel<__hip_bfloat16>, dim3(grid), dim3(256), 0, st, (const __hip_bfloat16 *)x, (const __hip_bfloat16 *)a, w, b,
+                           (__hip_bfloat16 *)y, mean, rstd, (long)rows, eps);
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
+
+// dw / db ([32] float32 each) must be zeroed by the caller; they are accumulated with atomics.
+extern "C" int pmx_ln32_backward(const void *x, const void *a, const void *dy, const float *w, const float *mean, const float *rstd,
+                                 void *dz, float *dw, float *db, int64_t rows, int32_t dtype, void *stream)
+{
+    if (!x || !a || !dy || !w || !mean || !rstd || !dz || !dw || !db || rows < 0) return PMX_ERR_INVALID;
+    if (rows == 0) return PMX_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const unsigned grid = (unsigned)std::min<int64_t>((rows + 255) / 256, 1024);
+    if (dtype == 0)
+        hipLaunchKernelGGL(pmx_ln32_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, (const float *)a, (const float *)dy, w, mean, rstd,
+                           (float *)dz, dw, db, (long)rows);
+    else
+        hipLaunchKernelGGL(pmx_ln32_bwd_kernel<__hip_bfloat16>, dim3(grid), dim3(256), 0, st, (const __hip_bfloat16 *)x, (const __hip_bfloat16 *)a,
+                           (const __hip_bfloat16 *)dy, w, mean, rstd, (__hip_bfloat16 *)dz, dw, db, (long)rows);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }

@@ -34,6 +34,50 @@ def layer_norm_small(x, ln):
     return ((xf - mean) * torch.rsqrt(var + ln.eps) * ln.weight + ln.bias).to(x.dtype)
 
 
+class _LN32Residual(torch.autograd.Function):
+    """LayerNorm(x + a) over a 32-wide feature dimension through the fused HIP kernels pmx_ln32_forward/backward."""
+
+    @staticmethod
+    def forward(ctx, x, a, w, b, eps):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        x, a = x.contiguous(), a.contiguous()
+        rows = x.numel() // 32
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        wf, bf = w.float().contiguous(), b.float().contiguous()
+        st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(lib.pmx_ln32_forward(x.data_ptr(), a.data_ptr(), wf.data_ptr(), bf.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                        rstd.data_ptr(), rows, float(eps), 0 if x.dtype == torch.float32 else 1, st), "pmx_ln32_forward")
+        ctx.save_for_backward(x, a, wf, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        x, a, wf, mean, rstd = ctx.saved_tensors
+        gy = gy.contiguous()
+        dz = torch.empty_like(x)
+        dwb = torch.zeros(2, 32, dtype=torch.float32, device=x.device)
+        st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(lib.pmx_ln32_backward(x.data_ptr(), a.data_ptr(), gy.data_ptr(), wf.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                         dz.data_ptr(), dwb[0].data_ptr(), dwb[1].data_ptr(), x.numel() // 32,
+                                         0 if x.dtype == torch.float32 else 1, st), "pmx_ln32_backward")
+        return dz, dz, dwb[0], dwb[1], None
+
+
+def add_layer_norm_small(x, a, ln):
+    """LayerNorm(x + a) for the critic tokens: the fused HIP kernel on the GPU (feature dimension 32, float32 or
+    bfloat16), the reduce + elementwise formulation otherwise."""
+    if x.is_cuda and x.shape[-1] == 32 and x.dtype == a.dtype and x.dtype in (torch.float32, torch.bfloat16):
+        return _LN32Residual.apply(x, a, ln.weight, ln.bias, ln.eps)
+    return layer_norm_small(x + a, ln)
+
+
 class _TokenLinear(torch.autograd.Function):
     """F.linear on a token tensor [S, B, in] with the weight gradient computed as S batched GEMMs of depth B followed by
     a sum over S.  hipBLASLt's choice for the flat [S*B, in]^T x [S*B, out] product (K = 630 k rows, a 32 x 128 result)
@@ -79,9 +123,9 @@ class CriticEncoderLayer(nn.TransformerEncoderLayer):
         a = F.scaled_dot_product_attention(q, k, v)                    # [B, h, S, d]
         a = a.permute(2, 0, 1, 3).reshape(S, B, E)
         a = token_linear(a, mha.out_proj.weight, mha.out_proj.bias)
-        x = layer_norm_small(x + a, self.norm1)
+        x = add_layer_norm_small(x, a, self.norm1)
         f = token_linear(F.relu(token_linear(x, self.linear1.weight, self.linear1.bias)), self.linear2.weight, self.linear2.bias)
-        return layer_norm_small(x + f, self.norm2)
+        return add_layer_norm_small(x, f, self.norm2)
 
 
 class ResidualBlock(nn.Module):

@@ -131,3 +131,28 @@ def test_evaluate_vs_bots_runs():
     model = mappo.MAPPOAgent((8, 7, 20), 5, 2).cuda()
     mean, std, wr = trainer.evaluate_vs_bots(model, num_episodes=2, layout_file="tinyCapture", teams=("randomTeam", "baselineTeam"), length=30)
     assert np.isfinite(mean) and np.isfinite(std) and 0.0 <= wr <= 1.0
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_fused_add_layernorm32_matches_torch(dtype, tol):
+    """pmx_ln32_forward/backward against torch.nn.functional.layer_norm(x + a) in float32."""
+    from pmx import mappo
+    torch.manual_seed(0)
+    S, B = 154, 257
+    ln = torch.nn.LayerNorm(32).cuda()
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(32).cuda() * 0.3 + 1.0); ln.bias.copy_(torch.randn(32).cuda() * 0.2)
+    x = torch.randn(S, B, 32, device="cuda").to(dtype).requires_grad_(True)
+    a = torch.randn(S, B, 32, device="cuda").to(dtype).requires_grad_(True)
+    g = torch.randn(S, B, 32, device="cuda").to(dtype)
+    y = mappo.add_layer_norm_small(x, a, ln)
+    y.backward(g)
+    got = (y.float(), x.grad.float(), a.grad.float(), ln.weight.grad.clone(), ln.bias.grad.clone())
+    ln.zero_grad()
+    x2 = x.detach().float().requires_grad_(True); a2 = a.detach().float().requires_grad_(True)
+    y2 = torch.nn.functional.layer_norm(x2 + a2, (32,), ln.weight, ln.bias, ln.eps)
+    y2.backward(g.float())
+    ref = (y2, x2.grad, a2.grad, ln.weight.grad, ln.bias.grad)
+    for name, u, v in zip(("y", "dx", "da", "dw", "db"), got, ref):
+        scale = float(v.abs().max()) + 1e-6
+        assert float((u - v).abs().max()) <= tol * scale * (8 if name in ("dw", "db") and dtype == torch.bfloat16 else 1), name
