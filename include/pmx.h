@@ -182,12 +182,14 @@ int pmx_merge_obs(const void *a_dev, const void *b_dev, void *out_dev, int32_t n
 /* Fused residual add + LayerNorm over a feature dimension of 32 (the critic's post-LN encoder layers,
  * pacman_mappo_resnet.py:138-141: norm(x + sublayer(x))): y = LayerNorm(x + a) * w + b on [rows][32] tensors of float32
  * (dtype 0) or bfloat16 (dtype 1); mean / rstd [rows] float32 are saved for the backward pass.  The backward pass
- * returns dz = d loss / d (x + a) (the gradient of both inputs) and ACCUMULATES dw, db ([32] float32, zeroed by the
- * caller). */
+ * returns dz = d loss / d (x + a) (the gradient of both inputs) and per-wavefront partial sums of the weight / bias
+ * gradients: partial_dev [PMX_LN32_PARTIAL_ROWS][64] float32 (dw in columns 0..31, db in 32..63), fully overwritten;
+ * the caller sums the rows. */
+#define PMX_LN32_PARTIAL_ROWS 2048
 int pmx_ln32_forward(const void *x_dev, const void *a_dev, const float *w_dev, const float *b_dev, void *y_dev, float *mean_dev,
                      float *rstd_dev, int64_t rows, float eps, int32_t dtype, void *stream);
 int pmx_ln32_backward(const void *x_dev, const void *a_dev, const void *dy_dev, const float *w_dev, const float *mean_dev,
-                      const float *rstd_dev, void *dz_dev, float *dw_dev, float *db_dev, int64_t rows, int32_t dtype, void *stream);
+                      const float *rstd_dev, void *dz_dev, float *partial_dev, int64_t rows, int32_t dtype, void *stream);
 
 #ifdef __cplusplus
 }

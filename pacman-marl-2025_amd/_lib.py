@@ -9,6 +9,7 @@ from . import build as _build
 PMX_MAX_DIM = 32
 OBS_F32, OBS_BF16, OBS_U8 = 0, 1, 2
 ACTION_RANDOM_LEGAL = -2
+LN32_PARTIAL_ROWS = 2048
 
 
 class PmxError(RuntimeError):
@@ -58,7 +59,7 @@ PROTOTYPES = [
     ("pmx_profile_end", C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(_I32), C.POINTER(C.c_double), C.POINTER(_I32)]),
     ("pmx_gae", C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, C.c_double, C.c_double, _VP, _VP, _VP]),
     ("pmx_ln32_forward", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_float, _I32, _VP]),
-    ("pmx_ln32_backward", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _I32, _VP]),
+    ("pmx_ln32_backward", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _I32, _VP]),
     ("pmx_canonicalize_obs", C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _VP]),
     ("pmx_merge_obs", C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
 ]

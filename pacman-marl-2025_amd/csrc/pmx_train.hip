@@ -306,8 +306,8 @@ __global__ __launch_bounds__(256) void pmx_ln32_fwd_kernel(const T *__restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void pmx_ln32_bwd_kernel(const T *__restrict__ x, const T *__restrict__ a, const T *__restrict__ dy,
                                                            const float *__restrict__ w, const float *__restrict__ mean_in,
-                                                           const float *__restrict__ rstd_in, T *__restrict__ dz, float *__restrict__ dw,
-                                                           float *__restrict__ db, long rows)
+                                                           const float *__restrict__ rstd_in, T *__restrict__ dz,
+                                                           float *__restrict__ partial /*[n_waves][64]*/, long rows)
 {
     constexpr int D = 32;
     float wv[D], gw[D], gb[D];
@@ -333,15 +333,17 @@ __global__ __launch_bounds__(256) void pmx_ln32_bwd_kernel(const T *__restrict__
         for (int j = 0; j < D; ++j) t[j] = rstd * (g[j] - c1 - z[j] * c2);
         LnIO<T>::store(dz + r * D, t);
     }
-    // wavefront reduction of the 64 accumulators, then one atomic per value per wave
+    // wavefront reduction of the 64 accumulators; every wave stores its partial sums (no atomics: 4 k waves adding into
+    // the same 64 floats serialise at the memory side -- 1.6 ms measured -- and would not be bitwise reproducible)
 #pragma unroll
     for (int j = 0; j < D; ++j) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { gw[j] += __shfl_xor(gw[j], o); gb[j] += __shfl_xor(gb[j], o); }
     }
     if ((threadIdx.x & 63) == 0) {
+        float *dst = partial + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64;
 #pragma unroll
-        for (int j = 0; j < D; ++j) { atomicAdd(&dw[j], gw[j]); atomicAdd(&db[j], gb[j]); }
+        for (int j = 0; j < D; ++j) { dst[j] = gw[j]; dst[32 + j] = gb[j]; }
     }
 }
 
@@ -361,19 +363,19 @@ extern "C" int pmx_ln32_forward(const void *x, const void *a, const float *w, co
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
 
-// dw / db ([32] float32 each) must be zeroed by the caller; they are accumulated with atomics.
+// partial: [PMX_LN32_PARTIAL_ROWS][64] float32, fully overwritten: row k holds one wavefront's sums of dw (first 32) and db
+// (last 32); the caller adds the rows up (a tiny reduction).
 extern "C" int pmx_ln32_backward(const void *x, const void *a, const void *dy, const float *w, const float *mean, const float *rstd,
-                                 void *dz, float *dw, float *db, int64_t rows, int32_t dtype, void *stream)
+                                 void *dz, float *partial, int64_t rows, int32_t dtype, void *stream)
 {
-    if (!x || !a || !dy || !w || !mean || !rstd || !dz || !dw || !db || rows < 0) return PMX_ERR_INVALID;
-    if (rows == 0) return PMX_OK;
+    if (!x || !a || !dy || !w || !mean || !rstd || !dz || !partial || rows < 0) return PMX_ERR_INVALID;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const unsigned grid = (unsigned)std::min<int64_t>((rows + 255) / 256, 1024);
+    const unsigned grid = PMX_LN32_PARTIAL_ROWS / 4;   // 4 wavefronts per block, every wave writes its row (zeros if idle)
     if (dtype == 0)
         hipLaunchKernelGGL(pmx_ln32_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, (const float *)a, (const float *)dy, w, mean, rstd,
-                           (float *)dz, dw, db, (long)rows);
+                           (float *)dz, partial, (long)rows);
     else
         hipLaunchKernelGGL(pmx_ln32_bwd_kernel<__hip_bfloat16>, dim3(grid), dim3(256), 0, st, (const __hip_bfloat16 *)x, (const __hip_bfloat16 *)a,
-                           (const __hip_bfloat16 *)dy, w, mean, rstd, (__hip_bfloat16 *)dz, dw, db, (long)rows);
+                           (const __hip_bfloat16 *)dy, w, mean, rstd, (__hip_bfloat16 *)dz, partial, (long)rows);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }

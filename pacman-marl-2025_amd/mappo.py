@@ -62,12 +62,13 @@ class _LN32Residual(torch.autograd.Function):
         x, a, wf, mean, rstd = ctx.saved_tensors
         gy = gy.contiguous()
         dz = torch.empty_like(x)
-        dwb = torch.zeros(2, 32, dtype=torch.float32, device=x.device)
+        partial = torch.empty(_lib.LN32_PARTIAL_ROWS, 64, dtype=torch.float32, device=x.device)
         st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         _lib.check(lib.pmx_ln32_backward(x.data_ptr(), a.data_ptr(), gy.data_ptr(), wf.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                         dz.data_ptr(), dwb[0].data_ptr(), dwb[1].data_ptr(), x.numel() // 32,
+                                         dz.data_ptr(), partial.data_ptr(), x.numel() // 32,
                                          0 if x.dtype == torch.float32 else 1, st), "pmx_ln32_backward")
-        return dz, dz, dwb[0], dwb[1], None
+        dwb = partial.sum(0)
+        return dz, dz, dwb[:32], dwb[32:], None
 
 
 def add_layer_norm_small(x, a, ln):
