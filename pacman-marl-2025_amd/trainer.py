@@ -54,7 +54,7 @@ def canonicalize_obs(o):
 class VecMAPPOTrainer:
     def __init__(self, layout, n_envs, horizon=32, minibatch=512, epochs=UPDATE_EPOCHS, obs_dtype="bfloat16",
                  device="cuda:0", seed=0, rank=0, world_size=1, process_group=None, total_updates=2000, length=300,
-                 use_autocast=True, opponent="random"):
+                 use_autocast=True, opponent="random", use_graph=True):
         self.device = torch.device(device)
         self.rank, self.world_size = rank, world_size
         self.env = PmxVecEnv(layout, n_envs, length=length, reward_forLegalAction=True, defenceReward=True,
@@ -98,6 +98,9 @@ class VecMAPPOTrainer:
         self.prev_agent = self.start_words[None].expand(N, 4).clone()
         self.update_idx = 0
         self.stats = {}
+        # the optimizer step is replayed from a hipGraph when every minibatch has the same shape
+        self.use_graph = bool(use_graph) and (horizon * n_envs * 2) % minibatch == 0
+        self._graph_ready = False
 
     # ---------------------------------------------------------------------------------------------------------
     def _net_in(self, x):
@@ -203,8 +206,12 @@ class VecMAPPOTrainer:
             perm = torch.randperm(S, device=self.device, generator=self.gen)
             for s0 in range(0, S, self.minibatch):
                 mb = perm[s0:s0 + self.minibatch]
-                st = self.learner.update_minibatch(self._net_in(obs[mb]), self._net_in(merged[mb // 2]), act[mb], logp[mb],
-                                                   adv[mb], ret[mb], clip_eps, ent_coef)
+                if self.use_graph and not self._graph_ready:
+                    self.learner.capture(self.minibatch, self.obs_shape, torch.bfloat16 if self.autocast_dtype is not None else torch.float32,
+                                         clip_eps, ent_coef)
+                    self._graph_ready = True
+                step = self.learner.update_minibatch_graph if self.use_graph else self.learner.update_minibatch
+                st = step(self._net_in(obs[mb]), self._net_in(merged[mb // 2]), act[mb], logp[mb], adv[mb], ret[mb], clip_eps, ent_coef)
                 steps += 1
                 agg = {k: v.clone() for k, v in st.items()} if agg is None else {k: agg[k] + st[k] for k in agg}
         self.stats.update({k: v / steps for k, v in agg.items()})
