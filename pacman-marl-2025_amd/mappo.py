@@ -399,7 +399,10 @@ class PPOLearner:
     def _set_graph_scalars(self, clip_eps, ent_coef, step):
         b1, b2 = self.betas
         bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
-        self._g_sc.copy_(torch.tensor([self.lr / bc1, 1.0 / math.sqrt(bc2), clip_eps, ent_coef], dtype=torch.float32))
+        # fill_ passes the value as a kernel argument: stream-ordered, no host staging buffer that could be recycled
+        # while a copy is still in flight
+        for k, v in enumerate((self.lr / bc1, 1.0 / math.sqrt(bc2), clip_eps, ent_coef)):
+            self._g_sc[k].fill_(float(v))
 
     def update_minibatch_graph(self, obs, merged, act, old_logp, adv, ret, clip_eps=CLIP_EPS, ent_coef=ENT_COEF_START):
         """Same step as update_minibatch, replayed from the captured graph (inputs are copied into its static buffers)."""
