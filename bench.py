@@ -83,11 +83,9 @@ def ppo_probe(layname, dev):
     merged = tr.merged_buf.view((tr.T * tr.N,) + tr.obs_shape)
     perm = torch.randperm(S, device=dev)
 
-    tr.learner.capture(mb, tr.obs_shape, torch.bfloat16)      # the whole optimizer step as one hipGraph
-
     def step(k):
         i = perm[k * mb:(k + 1) * mb]
-        tr.learner.update_minibatch_graph(tr._net_in(obs[i]), tr._net_in(merged[i // 2]), tr.act_buf.view(S)[i], tr.logp_buf.view(S)[i],
+        tr.learner.update_minibatch(tr._net_in(obs[i]), tr._net_in(merged[i // 2]), tr.act_buf.view(S)[i], tr.logp_buf.view(S)[i],
                                           tr.adv_buf.view(S)[i], tr.ret_buf.view(S)[i])
     for k in range(5):
         step(k)
@@ -100,8 +98,7 @@ def ppo_probe(layname, dev):
     tr.env.close()
     return {"optimizer_steps_per_s": steps / t_upd, "samples_per_optimizer_step": mb, "train_samples_per_s": steps * mb / t_upd,
             "rollout_env_steps_per_s": n_envs * horizon / t_roll, "rollout_envs": n_envs, "horizon": horizon,
-            "network": "MAPPOAgent (ResNet actor + transformer critic), bf16 autocast, PyTorch-ROCm ops + fused HIP "
-                       "add+LayerNorm, optimizer step replayed from a hipGraph",
+            "network": "MAPPOAgent (ResNet actor + transformer critic), bf16 autocast, PyTorch-ROCm ops + fused HIP add+LayerNorm",
             "reference_cpu": "about 0.5 optimizer-steps/s and 25 env-steps/s end to end on 8 host cores (SURVEY section 6)"}
 
 
