@@ -28,12 +28,24 @@ def stale():
 
 
 def build(force=False, verbose=False):
+    """Compile in-tree.  Serialised by a lock file and written through a temporary name, so that several ranks of one
+    job importing the package at once (torch.distributed.run) cannot corrupt the library."""
+    import fcntl
     if not force and not stale():
         return LIB
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not stale():          # another process built it while we waited
+                return LIB
+            tmp = LIB + ".tmp.%d" % os.getpid()
+            cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd, cwd=CSRC)
+            os.replace(tmp, LIB)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
