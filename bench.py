@@ -123,7 +123,7 @@ def main():
         raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:      # under torch.distributed.run the collective path is used even at N = 1
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
