@@ -54,13 +54,18 @@ def canonicalize_obs(o):
 class VecMAPPOTrainer:
     def __init__(self, layout, n_envs, horizon=32, minibatch=512, epochs=UPDATE_EPOCHS, obs_dtype="bfloat16",
                  device="cuda:0", seed=0, rank=0, world_size=1, process_group=None, total_updates=2000, length=300,
-                 use_autocast=True, opponent="random", use_graph=False):
+                 use_autocast=True, opponent="random", use_graph=False, algorithm="mappo"):
         self.device = torch.device(device)
         self.rank, self.world_size = rank, world_size
         self.env = PmxVecEnv(layout, n_envs, length=length, reward_forLegalAction=True, defenceReward=True,
                              auto_reset=True, obs_dtype=obs_dtype, device=self.device, seed=seed * 1000003 + rank)
         self.N, self.T = n_envs, horizon
         self.minibatch, self.epochs = minibatch, epochs
+        # "mappo": centralised critic on merge_obs_for_critic of the two learners (the reference).  "ippo": the same network
+        # with the critic fed each agent's OWN observation (BASELINE config 5 names the comparison; the reference has no
+        # IPPO, so this variant has no parity target -- SURVEY section 0)
+        assert algorithm in ("mappo", "ippo")
+        self.algorithm = algorithm
         self.total_updates = total_updates
         H, W = self.env.layout.height, self.env.layout.width
         self.obs_shape = (8, H, W)
@@ -151,10 +156,14 @@ class VecMAPPOTrainer:
             self.obs_buf[t].copy_(lo)
             merged = merge_obs(self.obs_buf[t, :, 0], self.obs_buf[t, :, 1])
             self.merged_buf[t].copy_(merged)
-            a, lp, v = self._forward_policy(self.model, self.obs_buf[t], merged, True)
+            if self.algorithm == "mappo":
+                a, lp, v = self._forward_policy(self.model, self.obs_buf[t], merged, True)
+                self.val_buf[t].copy_(v[:, None].expand(N, 2))
+            else:
+                a, lp, v = self._forward_policy(self.model, self.obs_buf[t], self.obs_buf[t].view((-1,) + self.obs_shape), True)
+                self.val_buf[t].copy_(v.view(N, 2))
             self.act_buf[t].copy_(a)
             self.logp_buf[t].copy_(lp)
-            self.val_buf[t].copy_(v[:, None].expand(N, 2))
             acts = torch.full((N, 4), _lib.ACTION_RANDOM_LEGAL, dtype=torch.int8, device=self.device)
             acts[:, learner_ids] = mappo.canonicalize_action(a, red).to(torch.int8)
             if mode in ("self", "pool"):
@@ -180,15 +189,18 @@ class VecMAPPOTrainer:
         lo = self.cur_obs[:, learner_ids]
         if red:
             lo = canonicalize_obs(lo)
-        last_merged = merge_obs(lo[:, 0].contiguous(), lo[:, 1].contiguous())
         ctx = torch.autocast(device_type=self.device.type, dtype=self.autocast_dtype) if self.autocast_dtype else _NullCtx()
         with torch.no_grad(), ctx:
-            self.last_value = self.model.value(self._net_in(last_merged)).float()
+            if self.algorithm == "mappo":
+                last_merged = merge_obs(lo[:, 0].contiguous(), lo[:, 1].contiguous())
+                self.last_value = self.model.value(self._net_in(last_merged)).float()[:, None].expand(N, 2).contiguous()
+            else:
+                self.last_value = self.model.value(self._net_in(lo.reshape((-1,) + self.obs_shape))).float().view(N, 2)
         self.stats.update(opponent=mode, play_as_red=red, rollout_reward=ep_ret, episodes=n_done, wins=n_win)
 
     def compute_gae(self):
         T, n = self.T, self.N * 2
-        last = self.last_value[:, None].expand(self.N, 2).contiguous()
+        last = self.last_value.contiguous()                         # [N, 2]
         st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(self.env.lib.pmx_gae(self.rew_buf.data_ptr(), self.val_buf.data_ptr(), self.done_buf.data_ptr(),
                                         last.data_ptr(), T, n, mappo.GAMMA, mappo.GAE_LAMBDA, self.adv_buf.data_ptr(),
@@ -213,7 +225,8 @@ class VecMAPPOTrainer:
                                          clip_eps, ent_coef)
                     self._graph_ready = True
                 step = self.learner.update_minibatch_graph if self.use_graph else self.learner.update_minibatch
-                st = step(self._net_in(obs[mb]), self._net_in(merged[mb // 2]), act[mb], logp[mb], adv[mb], ret[mb], clip_eps, ent_coef)
+                critic_in = merged[mb // 2] if self.algorithm == "mappo" else obs[mb]
+                st = step(self._net_in(obs[mb]), self._net_in(critic_in), act[mb], logp[mb], adv[mb], ret[mb], clip_eps, ent_coef)
                 steps += 1
                 agg = {k: v.clone() for k, v in st.items()} if agg is None else {k: agg[k] + st[k] for k in agg}
         self.stats.update({k: v / steps for k, v in agg.items()})

@@ -71,26 +71,27 @@ def test_ppo_loss_on_gpu_fp32_matches_reference():
     _close(float(learner.bucket.data.double().sum()), d["post_adam_sum"], rtol=1e-5)
 
 
-@pytest.mark.parametrize("opponent,dtype", [("random", "bfloat16"), ("self", "uint8")])
-def test_rollout_gae_update_end_to_end(opponent, dtype):
+@pytest.mark.parametrize("opponent,dtype,algorithm", [("random", "bfloat16", "mappo"), ("self", "uint8", "mappo"), ("random", "bfloat16", "ippo")])
+def test_rollout_gae_update_end_to_end(opponent, dtype, algorithm):
     import pmx
     from pmx import trainer
     tr = trainer.VecMAPPOTrainer("smallCapture", n_envs=256, horizon=12, minibatch=512, epochs=2, obs_dtype=dtype,
-                                 seed=5, length=20, opponent=opponent)
+                                 seed=5, length=20, opponent=opponent, algorithm=algorithm)
     for u in range(2):
         tr.rollout()
         tr.compute_gae()
         # GAE of the rollout buffers against the oracle, bit-exact, for a sample of series
         rew, val, done = tr.rew_buf.cpu().numpy(), tr.val_buf.cpu().numpy(), tr.done_buf.cpu().numpy()
-        adv, ret, last = tr.adv_buf.cpu().numpy(), tr.ret_buf.cpu().numpy(), tr.last_value.cpu().numpy()
+        adv, ret, last = tr.adv_buf.cpu().numpy(), tr.ret_buf.cpu().numpy(), tr.last_value.cpu().numpy()   # last [N,2]
         for e in range(0, 256, 37):
             for i in range(2):
-                a, r = O.gae(rew[:, e, i], val[:, e, i], done[:, e, i], float(last[e]), 0.99, 0.95)
+                a, r = O.gae(rew[:, e, i], val[:, e, i], done[:, e, i], float(last[e, i]), 0.99, 0.95)
                 assert a.tobytes() == adv[:, e, i].tobytes() and r.tobytes() == ret[:, e, i].tobytes()
         if u == 1:
             assert done.sum() > 0                                # length 20 -> every episode ends at tick 21
         # buffers: both learners share value and done; merged plane 4 is zero, plane 1 holds both learners
-        assert torch.equal(tr.val_buf[..., 0], tr.val_buf[..., 1]) and torch.equal(tr.done_buf[..., 0], tr.done_buf[..., 1])
+        assert torch.equal(tr.done_buf[..., 0], tr.done_buf[..., 1])
+        assert torch.equal(tr.val_buf[..., 0], tr.val_buf[..., 1]) == (algorithm == "mappo")
         m = tr.merged_buf.float()
         assert float(m[:, :, 4].abs().sum()) == 0
         assert torch.equal((m[:, :, 1] > 0).sum((-1, -2)) >= 1, torch.ones_like(m[:, :, 1, 0, 0], dtype=torch.bool))

@@ -20,6 +20,7 @@ ap.add_argument("--updates", type=int, default=10)
 ap.add_argument("--total-updates", type=int, default=2000)
 ap.add_argument("--opponent", default="curriculum", choices=["random", "self", "pool", "curriculum"])
 ap.add_argument("--obs", default="bfloat16")
+ap.add_argument("--algorithm", default="mappo", choices=["mappo", "ippo"])
 ap.add_argument("--eval-every", type=int, default=0)
 ap.add_argument("--save", default="")
 ap.add_argument("--seed", type=int, default=0)
@@ -36,7 +37,7 @@ from pmx import trainer
 
 tr = trainer.VecMAPPOTrainer(args.layout, args.envs, horizon=args.horizon, minibatch=args.minibatch, epochs=args.epochs,
                              obs_dtype=args.obs, device=f"cuda:{local}", seed=args.seed, rank=rank, world_size=world,
-                             total_updates=args.total_updates, opponent=args.opponent)
+                             total_updates=args.total_updates, opponent=args.opponent, algorithm=args.algorithm)
 for u in range(args.updates):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     st = tr.train_update()
