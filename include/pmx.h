@@ -191,6 +191,17 @@ int pmx_ln32_forward(const void *x_dev, const void *a_dev, const float *w_dev, c
 int pmx_ln32_backward(const void *x_dev, const void *a_dev, const void *dy_dev, const float *w_dev, const float *mean_dev,
                       const float *rstd_dev, void *dz_dev, float *partial_dev, int64_t rows, int32_t dtype, void *stream);
 
+/* Fused GroupNorm (8 channels per group) + optional residual add + exact GELU on [B][groups*8][H*W] tensors (NCHW),
+ * the elementwise tail of the actor's residual blocks (pacman_mappo_resnet.py:58-67): y = GELU(GN(h) * w + b (+ res)).
+ * dtype 0 float32, 1 bfloat16; res_dev / dres_dev may both be NULL.  Backward writes dh (and dres) and
+ * partial_dev [B*groups][8][2] float32 = per (sample, group, channel) sums of dz*xhat and dz, which the caller adds up
+ * over the batch to get the weight and bias gradients. */
+int pmx_gn8_gelu_forward(const void *h_dev, const void *res_dev, const float *w_dev, const float *b_dev, void *y_dev, float *mean_dev,
+                         float *rstd_dev, int64_t B, int32_t groups, int32_t HW, float eps, int32_t dtype, void *stream);
+int pmx_gn8_gelu_backward(const void *h_dev, const void *res_dev, const void *dy_dev, const float *w_dev, const float *b_dev,
+                          const float *mean_dev, const float *rstd_dev, void *dh_dev, void *dres_dev, float *partial_dev, int64_t B,
+                          int32_t groups, int32_t HW, int32_t dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -379,3 +379,165 @@ extern "C" int pmx_ln32_backward(const void *x, const void *a, const void *dy, c
                            (const __hip_bfloat16 *)dy, w, mean, rstd, (__hip_bfloat16 *)dz, partial, (long)rows);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused GroupNorm + (residual add) + GELU for the actor's residual blocks (pacman_mappo_resnet.py:49-67:
+// act(gn1(conv1(x))) and act(gn2(conv2(.)) + x)), NCHW, 8 channels per group (GroupNorm(4, 32)).
+// One WAVEFRONT per (sample, group) row = 8 * H*W contiguous elements, read once into registers
+// (v[channel][k], element lane + 64 k of the channel); float32 statistics via wavefront shuffles, exact (erf) GELU.
+// The backward kernel recomputes the normalised values, applies GELU', returns d/d(input), d/d(residual) and
+// per-sample partial sums of the weight / bias gradients ([B][C][2], summed over B by the caller: no atomics).
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float gn_ld(const T *p);
+template <> __device__ __forceinline__ float gn_ld<float>(const float *p) { return *p; }
+template <> __device__ __forceinline__ float gn_ld<__hip_bfloat16>(const __hip_bfloat16 *p) { return __bfloat162float(*p); }
+template <typename T> __device__ __forceinline__ void gn_st(T *p, float v);
+template <> __device__ __forceinline__ void gn_st<float>(float *p, float v) { *p = v; }
+template <> __device__ __forceinline__ void gn_st<__hip_bfloat16>(__hip_bfloat16 *p, float v) { *p = __float2bfloat16(v); }
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.0f + erff(z * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float z)
+{
+    return 0.5f * (1.0f + erff(z * 0.70710678118654752f)) + z * 0.39894228040143268f * __expf(-0.5f * z * z);
+}
+
+template <typename T, int KMAX>
+__global__ __launch_bounds__(256) void pmx_gn8_gelu_fwd_kernel(const T *__restrict__ h, const T *__restrict__ res, const float *__restrict__ w,
+                                                               const float *__restrict__ b, T *__restrict__ y, float *__restrict__ mean_out,
+                                                               float *__restrict__ rstd_out, long rows, int groups, int HW, float eps)
+{
+    constexpr int CPG = 8;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int g = (int)(row % groups);
+    const size_t base = (size_t)row * CPG * HW;            // (n * C + g * 8) * HW with C = groups * 8
+    float v[CPG][KMAX];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPG; ++c)
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int e = lane + 64 * k;
+            v[c][k] = e < HW ? gn_ld<T>(h + base + (size_t)c * HW + e) : 0.f;
+            s += v[c][k];
+        }
+    const float inv = 1.0f / (float)(CPG * HW);
+    const float mean = wave_sum(s) * inv;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPG; ++c)
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int e = lane + 64 * k;
+            const float d = e < HW ? v[c][k] - mean : 0.f;
+            q += d * d;
+        }
+    const float rstd = rsqrtf(wave_sum(q) * inv + eps);
+#pragma unroll
+    for (int c = 0; c < CPG; ++c) {
+        const float wc = w[g * CPG + c] * rstd, bc = b[g * CPG + c];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int e = lane + 64 * k;
+            if (e < HW) {
+                const size_t idx = base + (size_t)c * HW + e;
+                float z = (v[c][k] - mean) * wc + bc;
+                if (res) z += gn_ld<T>(res + idx);
+                gn_st<T>(y + idx, gelu_f(z));
+            }
+        }
+    }
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+template <typename T, int KMAX>
+__global__ __launch_bounds__(256) void pmx_gn8_gelu_bwd_kernel(const T *__restrict__ h, const T *__restrict__ res, const T *__restrict__ dy,
+                                                               const float *__restrict__ w, const float *__restrict__ b,
+                                                               const float *__restrict__ mean_in, const float *__restrict__ rstd_in,
+                                                               T *__restrict__ dh, T *__restrict__ dres, float *__restrict__ partial /*[rows][8][2]*/,
+                                                               long rows, int groups, int HW)
+{
+    constexpr int CPG = 8;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int g = (int)(row % groups);
+    const size_t base = (size_t)row * CPG * HW;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float xh[CPG][KMAX], gz[CPG][KMAX];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPG; ++c) {
+        const float wc = w[g * CPG + c], bc = b[g * CPG + c];
+        float sw = 0.f, sb = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int e = lane + 64 * k;
+            xh[c][k] = 0.f; gz[c][k] = 0.f;
+            if (e < HW) {
+                const size_t idx = base + (size_t)c * HW + e;
+                const float x = (gn_ld<T>(h + idx) - mean) * rstd;
+                float z = x * wc + bc;
+                if (res) z += gn_ld<T>(res + idx);
+                const float dz = gn_ld<T>(dy + idx) * gelu_grad_f(z);
+                if (dres) gn_st<T>(dres + idx, dz);
+                sw += dz * x; sb += dz;
+                const float gg = dz * wc;
+                xh[c][k] = x; gz[c][k] = gg;
+                c1 += gg; c2 += gg * x;
+            }
+        }
+        sw = wave_sum(sw); sb = wave_sum(sb);
+        if (lane == 0) { partial[((size_t)row * CPG + c) * 2] = sw; partial[((size_t)row * CPG + c) * 2 + 1] = sb; }
+    }
+    const float inv = 1.0f / (float)(CPG * HW);
+    c1 = wave_sum(c1) * inv; c2 = wave_sum(c2) * inv;
+#pragma unroll
+    for (int c = 0; c < CPG; ++c)
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int e = lane + 64 * k;
+            if (e < HW) gn_st<T>(dh + base + (size_t)c * HW + e, rstd * (gz[c][k] - c1 - xh[c][k] * c2));
+        }
+}
+
+// [B][C][H*W] tensors with C = groups * 8; dtype 0 float32, 1 bfloat16; res_dev may be NULL (no residual).
+extern "C" int pmx_gn8_gelu_forward(const void *h, const void *res, const float *w, const float *b, void *y, float *mean, float *rstd,
+                                    int64_t B, int32_t groups, int32_t HW, float eps, int32_t dtype, void *stream)
+{
+    if (!h || !w || !b || !y || !mean || !rstd || B < 0 || groups < 1 || HW < 1 || HW > 1024) return PMX_ERR_INVALID;
+    const long rows = (long)B * groups;
+    if (rows == 0) return PMX_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+#define PMX_GN_FWD(T, K) hipLaunchKernelGGL((pmx_gn8_gelu_fwd_kernel<T, K>), dim3(grid), dim3(256), 0, st, (const T *)h, (const T *)res, w, b, (T *)y, mean, rstd, rows, groups, HW, eps)
+    if (dtype == 0) { if (HW <= 192) PMX_GN_FWD(float, 3); else if (HW <= 448) PMX_GN_FWD(float, 7); else PMX_GN_FWD(float, 16); }
+    else { if (HW <= 192) PMX_GN_FWD(__hip_bfloat16, 3); else if (HW <= 448) PMX_GN_FWD(__hip_bfloat16, 7); else PMX_GN_FWD(__hip_bfloat16, 16); }
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
+
+// dh (and dres when res_dev is given) are written in full; partial [B * groups][8][2] float32 receives, per (sample, group)
+// row and channel of the group, the sums of dz * xhat (weight gradient) and dz (bias gradient).
+extern "C" int pmx_gn8_gelu_backward(const void *h, const void *res, const void *dy, const float *w, const float *b, const float *mean,
+                                     const float *rstd, void *dh, void *dres, float *partial, int64_t B, int32_t groups, int32_t HW,
+                                     int32_t dtype, void *stream)
+{
+    if (!h || !dy || !w || !b || !mean || !rstd || !dh || !partial || B < 0 || groups < 1 || HW < 1 || HW > 1024) return PMX_ERR_INVALID;
+    if ((res == nullptr) != (dres == nullptr)) return PMX_ERR_INVALID;
+    const long rows = (long)B * groups;
+    if (rows == 0) return PMX_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+#define PMX_GN_BWD(T, K) hipLaunchKernelGGL((pmx_gn8_gelu_bwd_kernel<T, K>), dim3(grid), dim3(256), 0, st, (const T *)h, (const T *)res, (const T *)dy, w, b, mean, rstd, (T *)dh, (T *)dres, partial, rows, groups, HW)
+    if (dtype == 0) { if (HW <= 192) PMX_GN_BWD(float, 3); else if (HW <= 448) PMX_GN_BWD(float, 7); else PMX_GN_BWD(float, 16); }
+    else { if (HW <= 192) PMX_GN_BWD(__hip_bfloat16, 3); else if (HW <= 448) PMX_GN_BWD(__hip_bfloat16, 7); else PMX_GN_BWD(__hip_bfloat16, 16); }
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}

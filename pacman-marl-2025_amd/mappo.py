@@ -129,6 +129,59 @@ class CriticEncoderLayer(nn.TransformerEncoderLayer):
         return add_layer_norm_small(x, f, self.norm2)
 
 
+class _GN8Gelu(torch.autograd.Function):
+    """GELU(GroupNorm(h) (+ res)) with 8 channels per group through pmx_gn8_gelu_forward/backward."""
+
+    @staticmethod
+    def forward(ctx, h, res, w, b, groups, eps):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        h = h.contiguous()
+        res = res.contiguous() if res is not None else None
+        B, Cc = h.shape[0], h.shape[1]
+        HW = h.numel() // (B * Cc)
+        y = torch.empty_like(h)
+        mean = torch.empty(B * groups, dtype=torch.float32, device=h.device)
+        rstd = torch.empty(B * groups, dtype=torch.float32, device=h.device)
+        wf, bf = w.float().contiguous(), b.float().contiguous()
+        st = C.c_void_p(torch.cuda.current_stream(h.device).cuda_stream)
+        _lib.check(lib.pmx_gn8_gelu_forward(h.data_ptr(), res.data_ptr() if res is not None else None, wf.data_ptr(), bf.data_ptr(),
+                                            y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, groups, HW, float(eps),
+                                            0 if h.dtype == torch.float32 else 1, st), "pmx_gn8_gelu_forward")
+        ctx.save_for_backward(h, res if res is not None else h.new_empty(0), wf, bf, mean, rstd)
+        ctx.has_res, ctx.groups, ctx.HW = res is not None, groups, HW
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        h, res, wf, bf, mean, rstd = ctx.saved_tensors
+        gy = gy.contiguous()
+        B, Cc = h.shape[0], h.shape[1]
+        dh = torch.empty_like(h)
+        dres = torch.empty_like(h) if ctx.has_res else None
+        partial = torch.empty(B, Cc, 2, dtype=torch.float32, device=h.device)
+        st = C.c_void_p(torch.cuda.current_stream(h.device).cuda_stream)
+        _lib.check(lib.pmx_gn8_gelu_backward(h.data_ptr(), res.data_ptr() if ctx.has_res else None, gy.data_ptr(), wf.data_ptr(),
+                                             bf.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dh.data_ptr(),
+                                             dres.data_ptr() if ctx.has_res else None, partial.data_ptr(), B, ctx.groups, ctx.HW,
+                                             0 if h.dtype == torch.float32 else 1, st), "pmx_gn8_gelu_backward")
+        g = partial.sum(0)
+        return dh, dres, g[:, 0], g[:, 1], None, None
+
+
+def group_norm_gelu(h, res, gn):
+    """GELU(gn(h) (+ res)): the fused HIP kernels on the GPU when the group has 8 channels, torch ops otherwise."""
+    if (h.is_cuda and h.dim() == 4 and gn.num_channels == 8 * gn.num_groups and h.dtype in (torch.float32, torch.bfloat16)
+            and (res is None or res.dtype == h.dtype) and h.shape[2] * h.shape[3] <= 1024):
+        return _GN8Gelu.apply(h, res, gn.weight, gn.bias, gn.num_groups, gn.eps)
+    z = gn(h)
+    return F.gelu(z if res is None else z + res)
+
+
 class ResidualBlock(nn.Module):
     """conv3x3 - GroupNorm(4) - GELU - conv3x3 - GroupNorm(4) - (+x) - GELU   (pacman_mappo_resnet.py:49-67)"""
 
@@ -141,9 +194,8 @@ class ResidualBlock(nn.Module):
         self.gn2 = nn.GroupNorm(4, channels)
 
     def forward(self, x):
-        y = self.act(self.gn1(self.conv1(x)))
-        y = self.gn2(self.conv2(y))
-        return self.act(y + x)
+        y = group_norm_gelu(self.conv1(x), None, self.gn1)
+        return group_norm_gelu(self.conv2(y), x, self.gn2)
 
 
 class PositionalEncoding2D(nn.Module):

@@ -157,3 +157,33 @@ def test_fused_add_layernorm32_matches_torch(dtype, tol):
     for name, u, v in zip(("y", "dx", "da", "dw", "db"), got, ref):
         scale = float(v.abs().max()) + 1e-6
         assert float((u - v).abs().max()) <= tol * scale * (8 if name in ("dw", "db") and dtype == torch.bfloat16 else 1), name
+
+
+@pytest.mark.parametrize("dtype,tol,hw", [(torch.float32, 3e-5, (11, 14)), (torch.bfloat16, 3e-2, (11, 14)), (torch.float32, 3e-5, (20, 20)), (torch.float32, 3e-5, (32, 32))])
+def test_fused_groupnorm_gelu_matches_torch(dtype, tol, hw):
+    """pmx_gn8_gelu_forward/backward against gelu(group_norm(h) + res) computed by torch in float32, with and without residual."""
+    from pmx import mappo
+    torch.manual_seed(1)
+    B, C = 37, 32
+    gn = torch.nn.GroupNorm(4, C).cuda()
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(C).cuda() * 0.3 + 1.0); gn.bias.copy_(torch.randn(C).cuda() * 0.2)
+    for with_res in (False, True):
+        h = (torch.randn(B, C, *hw, device="cuda") * 1.5 + 0.3).to(dtype).requires_grad_(True)
+        r = torch.randn(B, C, *hw, device="cuda").to(dtype).requires_grad_(True) if with_res else None
+        g = torch.randn(B, C, *hw, device="cuda").to(dtype)
+        gn.zero_grad()
+        y = mappo.group_norm_gelu(h, r, gn)
+        y.backward(g)
+        got = [y.float(), h.grad.float(), gn.weight.grad.clone(), gn.bias.grad.clone()] + ([r.grad.float()] if with_res else [])
+        gn.zero_grad()
+        h2 = h.detach().float().requires_grad_(True)
+        r2 = r.detach().float().requires_grad_(True) if with_res else None
+        z = torch.nn.functional.group_norm(h2, 4, gn.weight, gn.bias, gn.eps)
+        y2 = torch.nn.functional.gelu(z + r2 if with_res else z)
+        y2.backward(g.float())
+        ref = [y2, h2.grad, gn.weight.grad, gn.bias.grad] + ([r2.grad] if with_res else [])
+        for name, u, v in zip(("y", "dh", "dw", "db", "dres"), got, ref):
+            scale = float(v.abs().max()) + 1e-6
+            mult = 8 if name in ("dw", "db") and dtype == torch.bfloat16 else 1
+            assert float((u - v).abs().max()) <= tol * scale * mult, (name, with_res, float((u - v).abs().max()), scale)
