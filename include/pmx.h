@@ -202,6 +202,12 @@ int pmx_gn8_gelu_backward(const void *h_dev, const void *res_dev, const void *dy
                           const float *mean_dev, const float *rstd_dev, void *dh_dev, void *dres_dev, float *partial_dev, int64_t B,
                           int32_t groups, int32_t HW, int32_t dtype, void *stream);
 
+/* Self-attention forward of the critic's encoder layers (nn.MultiheadAttention, embed 32, 4 heads of 8,
+ * pacman_mappo_resnet.py:138-141) on the matrix cores: qkv_dev [S][B][96] bfloat16 = packed in-projection output,
+ * out_dev [S][B][32] bfloat16 = concatenated heads before the out-projection, lse_dev [B][4][S] float32 (may be NULL).
+ * S <= 1024. */
+int pmx_attn8_forward(const void *qkv_dev, void *out_dev, float *lse_dev, int32_t S, int32_t B, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

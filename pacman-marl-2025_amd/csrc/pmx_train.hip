@@ -541,3 +541,144 @@ extern "C" int pmx_gn8_gelu_backward(const void *h, const void *res, const void 
     else { if (HW <= 192) PMX_GN_BWD(__hip_bfloat16, 3); else if (HW <= 448) PMX_GN_BWD(__hip_bfloat16, 7); else PMX_GN_BWD(__hip_bfloat16, 16); }
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Small-sequence self-attention forward on the matrix cores (the critic: S = H*W <= 1024 tokens, 4 heads x 8,
+// pacman_mappo_resnet.py:138-141), bf16 in, f32 accumulate.  One WAVEFRONT per (sample, head), the four heads of a
+// sample in one block; q, k, v are read straight from the packed in-projection output [S][B][3E] and the result is
+// written as [S][B][E], so no head split / merge copies exist.
+//   S^T tile = K_tile . Q_tile^T      v_mfma_f32_16x16x32_bf16, head_dim 8 zero-padded to the K = 32 of the instruction;
+//                                     the accumulator holds S^T[key = 4*(lane>>4)+reg][query = lane&15]
+//   online softmax per query column   (max / sum over the 8 keys a lane holds, then over the four lane groups: 2 shuffles)
+//   O^T += V^T . P^T                  the exp'd accumulators of two key tiles ARE the B fragment of the next MFMA: the
+//                                     contraction index (keys) may be enumerated in any order as long as the A operand
+//                                     (V^T, staged transposed in LDS) uses the same one -- no LDS round trip for P.
+// ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) short pmx_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float pmx_f32x4;
+
+__device__ __forceinline__ short pmx_f2bf(float f)
+{
+    const __hip_bfloat16 h = __float2bfloat16(f);
+    return *reinterpret_cast<const short *>(&h);
+}
+
+__global__ __launch_bounds__(256) void pmx_attn8_fwd_kernel(const __hip_bfloat16 *__restrict__ qkv, __hip_bfloat16 *__restrict__ out,
+                                                            float *__restrict__ lse, int S, int B, float scale)
+{
+    constexpr int D = 8, HEADS = 4, E = 32;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x, h = wave;
+    const int S_pad = (S + 31) & ~31;
+    // per wave: K [S_pad][8] bf16, then V^T [8][S_pad] bf16
+    short *Ks = reinterpret_cast<short *>(smem) + (size_t)wave * 2 * S_pad * D;
+    short *Vt = Ks + (size_t)S_pad * D;
+    const short *base = reinterpret_cast<const short *>(qkv);
+    const size_t row_stride = (size_t)B * 3 * E;                     // elements between consecutive sequence positions
+    const size_t head_off = (size_t)b * 3 * E + (size_t)h * D;
+    for (int s = lane; s < S_pad; s += 64) {
+        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (s < S) {
+            kv = *reinterpret_cast<const uint4 *>(base + (size_t)s * row_stride + head_off + E);
+            vv = *reinterpret_cast<const uint4 *>(base + (size_t)s * row_stride + head_off + 2 * E);
+        }
+        *reinterpret_cast<uint4 *>(Ks + (size_t)s * D) = kv;
+        const short *vs = reinterpret_cast<const short *>(&vv);
+#pragma unroll
+        for (int d = 0; d < D; ++d) Vt[(size_t)d * S_pad + s] = vs[d];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const int g = lane >> 4, c = lane & 15;
+    const pmx_bf16x8 zero8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    const int n_qt = (S + 15) >> 4, n_kp = S_pad >> 5;
+    for (int qt = 0; qt < n_qt; ++qt) {
+        const int q_row = qt * 16 + c;
+        pmx_bf16x8 qf = zero8;
+        if (g == 0 && q_row < S) qf = *reinterpret_cast<const pmx_bf16x8 *>(base + (size_t)q_row * row_stride + head_off);
+        float m = -1e30f, l = 0.f;
+        pmx_f32x4 o = { 0.f, 0.f, 0.f, 0.f };
+        for (int kp = 0; kp < n_kp; ++kp) {
+            pmx_bf16x8 k0 = zero8, k1 = zero8;
+            if (g == 0) {
+                k0 = *reinterpret_cast<const pmx_bf16x8 *>(Ks + (size_t)(kp * 32 + c) * D);
+                k1 = *reinterpret_cast<const pmx_bf16x8 *>(Ks + (size_t)(kp * 32 + 16 + c) * D);
+            }
+            const pmx_f32x4 z4 = { 0.f, 0.f, 0.f, 0.f };
+            pmx_f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf, z4, 0, 0, 0);
+            pmx_f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf, z4, 0, 0, 0);
+            float p[8];
+            float mloc = -1e30f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key0 = kp * 32 + g * 4 + r, key1 = key0 + 16;
+                p[r] = key0 < S ? s0[r] * scale : -1e30f;
+                p[4 + r] = key1 < S ? s1[r] * scale : -1e30f;
+                mloc = fmaxf(mloc, fmaxf(p[r], p[4 + r]));
+            }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            const float mnew = fmaxf(m, mloc);
+            const float alpha = __expf(m - mnew);
+            float lsum = 0.f;
+            pmx_bf16x8 pf;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float e = __expf(p[r] - mnew);
+                lsum += e;
+                pf[r] = pmx_f2bf(e);
+            }
+            lsum += __shfl_xor(lsum, 16);
+            lsum += __shfl_xor(lsum, 32);
+            l = l * alpha + lsum;
+            m = mnew;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] *= alpha;
+            // A = V^T: row d = c (zero for d >= 8), k-slot j -> key kp*32 + 4g + j (j < 4), kp*32 + 16 + 4g + (j-4)
+            pmx_bf16x8 vf = zero8;
+            if (c < D) {
+                const short *vrow = Vt + (size_t)c * S_pad + kp * 32 + g * 4;
+                const uint2 lo = *reinterpret_cast<const uint2 *>(vrow);
+                const uint2 hi = *reinterpret_cast<const uint2 *>(vrow + 16);
+                const uint4 both = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                vf = *reinterpret_cast<const pmx_bf16x8 *>(&both);
+            }
+            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o, 0, 0, 0);
+        }
+        // O^T[d = 4g + r][query c]: lanes of groups 0 and 1 hold d = 0..3 and 4..7
+        if (q_row < S) {
+            const float inv = 1.0f / l;
+            if (g < 2) {
+                short w4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w4[r] = pmx_f2bf(o[r] * inv);
+                *reinterpret_cast<uint2 *>(reinterpret_cast<short *>(out) + ((size_t)q_row * B + b) * E + h * D + g * 4) =
+                    *reinterpret_cast<const uint2 *>(w4);
+            }
+            if (g == 0 && lse) lse[((size_t)b * HEADS + h) * S + q_row] = m + __logf(l);
+        }
+    }
+}
+
+// qkv_dev [S][B][96] bf16 (the packed in-projection of nn.MultiheadAttention with embed 32, 4 heads), out_dev [S][B][32]
+// bf16, lse_dev [B][4][S] float32 (log-sum-exp of the scaled scores per query; may be NULL).
+extern "C" int pmx_attn8_forward(const void *qkv_dev, void *out_dev, float *lse_dev, int32_t S, int32_t B, void *stream)
+{
+    if (!qkv_dev || !out_dev || S < 1 || S > 1024 || B < 0) return PMX_ERR_INVALID;
+    if (B == 0) return PMX_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int S_pad = (S + 31) & ~31;
+    const size_t lds = (size_t)4 * 2 * S_pad * 8 * sizeof(short);
+    static bool attr_set = false;
+    if (lds > 65536 && !attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(pmx_attn8_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return PMX_ERR_HIP;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(pmx_attn8_fwd_kernel, dim3(B), dim3(256), lds, st, (const __hip_bfloat16 *)qkv_dev, (__hip_bfloat16 *)out_dev, lse_dev, S, B,
+                       0.35355339059327379f /* 1/sqrt(8) */);
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}

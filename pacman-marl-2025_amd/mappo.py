@@ -79,6 +79,21 @@ def add_layer_norm_small(x, a, ln):
     return layer_norm_small(x + a, ln)
 
 
+def attention8_forward(qkv, want_lse=False):
+    """softmax(q k^T / sqrt(8)) v for 4 heads of 8 on the matrix cores (pmx_attn8_forward): qkv [S, B, 96] bfloat16 ->
+    [S, B, 32] bfloat16 (+ log-sum-exp [B, 4, S] float32)."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    S, B, _ = qkv.shape
+    qkv = qkv.contiguous()
+    out = torch.empty(S, B, 32, dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty(B, 4, S, dtype=torch.float32, device=qkv.device) if want_lse else None
+    st = C.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)
+    _lib.check(lib.pmx_attn8_forward(qkv.data_ptr(), out.data_ptr(), lse.data_ptr() if want_lse else None, S, B, st), "pmx_attn8_forward")
+    return (out, lse) if want_lse else out
+
+
 class _TokenLinear(torch.autograd.Function):
     """F.linear on a token tensor [S, B, in] with the weight gradient computed as S batched GEMMs of depth B followed by
     a sum over S.  hipBLASLt's choice for the flat [S*B, in]^T x [S*B, out] product (K = 630 k rows, a 32 x 128 result)
@@ -119,6 +134,12 @@ class CriticEncoderLayer(nn.TransformerEncoderLayer):
         mha = self.self_attn
         h, d = mha.num_heads, E // mha.num_heads
         qkv = token_linear(x, mha.in_proj_weight, mha.in_proj_bias)
+        if (not torch.is_grad_enabled()) and qkv.is_cuda and qkv.dtype == torch.bfloat16 and E == 32 and h == 4 and S <= 1024:
+            a = attention8_forward(qkv)                                # inference: hand-written MFMA attention
+            a = token_linear(a, mha.out_proj.weight, mha.out_proj.bias)
+            x = add_layer_norm_small(x, a, self.norm1)
+            f = token_linear(F.relu(token_linear(x, self.linear1.weight, self.linear1.bias)), self.linear2.weight, self.linear2.bias)
+            return add_layer_norm_small(x, f, self.norm2)
         q, k, v = qkv.chunk(3, dim=-1)
         q, k, v = (t.reshape(S, B * h, d).transpose(0, 1).reshape(B, h, S, d) for t in (q, k, v))
         a = F.scaled_dot_product_attention(q, k, v)                    # [B, h, S, d]

@@ -187,3 +187,20 @@ def test_fused_groupnorm_gelu_matches_torch(dtype, tol, hw):
             scale = float(v.abs().max()) + 1e-6
             mult = 8 if name in ("dw", "db") and dtype == torch.bfloat16 else 1
             assert float((u - v).abs().max()) <= tol * scale * mult, (name, with_res, float((u - v).abs().max()), scale)
+
+
+@pytest.mark.parametrize("S,B", [(154, 37), (140, 5), (400, 9), (33, 3), (1024, 2)])
+def test_mfma_attention_forward_matches_torch(S, B):
+    """pmx_attn8_forward against softmax(q k^T / sqrt(8)) v computed by torch in float32 from the same bf16 inputs.
+    Random (asymmetric) data: a transposed or permuted fragment layout cannot pass."""
+    from pmx import mappo
+    torch.manual_seed(S)
+    qkv = (torch.randn(S, B, 96, device="cuda") * 1.7).to(torch.bfloat16)
+    out, lse = mappo.attention8_forward(qkv, want_lse=True)
+    q, k, v = qkv.float().chunk(3, dim=-1)
+    q, k, v = (t.reshape(S, B, 4, 8).permute(1, 2, 0, 3) for t in (q, k, v))          # [B, h, S, d]
+    sc = torch.matmul(q, k.transpose(-1, -2)) / 8 ** 0.5
+    ref = torch.matmul(torch.softmax(sc, -1), v).permute(2, 0, 1, 3).reshape(S, B, 32)
+    err = float((out.float() - ref).abs().max())
+    assert err <= 2e-2 * (float(ref.abs().max()) + 1e-6), err                          # bf16 probabilities / outputs
+    assert float((lse - torch.logsumexp(sc, -1)).abs().max()) <= 2e-3
