@@ -207,6 +207,9 @@ int pmx_gn8_gelu_backward(const void *h_dev, const void *res_dev, const void *dy
  * out_dev [S][B][32] bfloat16 = concatenated heads before the out-projection, lse_dev [B][4][S] float32 (may be NULL).
  * S <= 1024. */
 int pmx_attn8_forward(const void *qkv_dev, void *out_dev, float *lse_dev, int32_t S, int32_t B, void *stream);
+/* Its backward pass: dqkv_dev [S][B][96] bfloat16 from the saved qkv, out, lse and the incoming dout [S][B][32].  S <= 640. */
+int pmx_attn8_backward(const void *qkv_dev, const void *out_dev, const void *dout_dev, const float *lse_dev, void *dqkv_dev,
+                       int32_t S, int32_t B, void *stream);
 
 #ifdef __cplusplus
 }

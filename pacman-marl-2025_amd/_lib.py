@@ -63,6 +63,7 @@ PROTOTYPES = [
     ("pmx_gn8_gelu_forward", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _I32, _I32, C.c_float, _I32, _VP]),
     ("pmx_gn8_gelu_backward", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _I32, _I32, _I32, _VP]),
     ("pmx_attn8_forward", C.c_int, [_VP, _VP, _VP, _I32, _I32, _VP]),
+    ("pmx_attn8_backward", C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _VP]),
     ("pmx_canonicalize_obs", C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _VP]),
     ("pmx_merge_obs", C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
 ]

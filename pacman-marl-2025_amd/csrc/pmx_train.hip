@@ -682,3 +682,173 @@ extern "C" int pmx_attn8_forward(const void *qkv_dev, void *out_dev, float *lse_
                        0.35355339059327379f /* 1/sqrt(8) */);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of the small-sequence attention (same shapes as pmx_attn8_fwd_kernel), recomputing the probabilities from
+// the saved log-sum-exp.  One wavefront per (sample, head), two passes, every product on v_mfma_f32_16x16x32_bf16:
+//   pass A (per 16-query tile, lanes = queries):  S^T, dP^T tiles over key pairs -> dS^T = P^T o (dP^T - Delta_q)
+//                                                 dQ^T += K^T . dS^T          (the accumulators are the B fragment)
+//   pass B (per 16-key tile, lanes = keys):       S, dP tiles over query pairs -> P, dS = P o (dP - Delta_q)
+//                                                 dV^T += dO^T . P,  dK^T += Q^T . dS
+// K^T, Q^T, dO^T are staged transposed in LDS ([8][S_pad] bf16), Delta_q = sum_d dO.O and the LSE as float32 [S_pad];
+// the row-major operands of the score products are read straight from global memory (16 bytes per lane, L1-resident).
+// Gradients are written in the packed [S][B][96] layout of the in-projection output.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pmx_attn8_bwd_kernel(const __hip_bfloat16 *__restrict__ qkv, const __hip_bfloat16 *__restrict__ outp,
+                                                            const __hip_bfloat16 *__restrict__ dout, const float *__restrict__ lse,
+                                                            __hip_bfloat16 *__restrict__ dqkv, int S, int B, float scale)
+{
+    constexpr int D = 8, HEADS = 4, E = 32;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x, h = wave;
+    const int S_pad = (S + 31) & ~31;
+    const size_t per_wave = (size_t)3 * D * S_pad * sizeof(short) + (size_t)2 * S_pad * sizeof(float);
+    unsigned char *mine = smem + (size_t)wave * per_wave;
+    short *Kt = reinterpret_cast<short *>(mine);                    // [8][S_pad]
+    short *Qt = Kt + (size_t)D * S_pad;
+    short *dOt = Qt + (size_t)D * S_pad;
+    float *lse_s = reinterpret_cast<float *>(dOt + (size_t)D * S_pad);
+    float *delta_s = lse_s + S_pad;
+    const short *base = reinterpret_cast<const short *>(qkv);
+    const short *obase = reinterpret_cast<const short *>(outp);
+    const short *dobase = reinterpret_cast<const short *>(dout);
+    const size_t row_stride = (size_t)B * 3 * E, orow = (size_t)B * E;
+    const size_t head_off = (size_t)b * 3 * E + (size_t)h * D, ohead = (size_t)b * E + (size_t)h * D;
+
+    for (int s = lane; s < S_pad; s += 64) {
+        uint4 qv = make_uint4(0, 0, 0, 0), kv = qv, dov = qv, ov = qv;
+        float ls = 1e30f;                                            // padded queries: exp(score - 1e30) = 0
+        if (s < S) {
+            qv = *reinterpret_cast<const uint4 *>(base + (size_t)s * row_stride + head_off);
+            kv = *reinterpret_cast<const uint4 *>(base + (size_t)s * row_stride + head_off + E);
+            dov = *reinterpret_cast<const uint4 *>(dobase + (size_t)s * orow + ohead);
+            ov = *reinterpret_cast<const uint4 *>(obase + (size_t)s * orow + ohead);
+            ls = lse[((size_t)b * HEADS + h) * S + s];
+        }
+        const short *q8 = reinterpret_cast<const short *>(&qv), *k8 = reinterpret_cast<const short *>(&kv);
+        const short *d8 = reinterpret_cast<const short *>(&dov), *o8 = reinterpret_cast<const short *>(&ov);
+        float delta = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            Kt[(size_t)d * S_pad + s] = k8[d];
+            Qt[(size_t)d * S_pad + s] = q8[d];
+            dOt[(size_t)d * S_pad + s] = d8[d];
+            delta += __uint_as_float((uint32_t)(uint16_t)d8[d] << 16) * __uint_as_float((uint32_t)(uint16_t)o8[d] << 16);
+        }
+        lse_s[s] = ls; delta_s[s] = delta;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const int g = lane >> 4, c = lane & 15;
+    const pmx_bf16x8 zero8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    const pmx_f32x4 z4 = { 0.f, 0.f, 0.f, 0.f };
+    const int n_t = (S + 15) >> 4, n_p = S_pad >> 5;
+    short *dbase = reinterpret_cast<short *>(dqkv);
+
+    auto row8 = [&](const short *src, size_t stride, size_t off, int r) -> pmx_bf16x8 {   // 8 bf16 of row r for lanes of group 0
+        pmx_bf16x8 v = zero8;
+        if (g == 0 && r < S) v = *reinterpret_cast<const pmx_bf16x8 *>(src + (size_t)r * stride + off);
+        return v;
+    };
+    auto tfrag = [&](const short *T, int pair) -> pmx_bf16x8 {       // A fragment [row d = c][k-slot j]: index 32*pair + 4g + j / + 16
+        pmx_bf16x8 v = zero8;
+        if (c < D) {
+            const short *p = T + (size_t)c * S_pad + pair * 32 + g * 4;
+            const uint2 lo = *reinterpret_cast<const uint2 *>(p), hi = *reinterpret_cast<const uint2 *>(p + 16);
+            const uint4 both = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            v = *reinterpret_cast<const pmx_bf16x8 *>(&both);
+        }
+        return v;
+    };
+
+    // ---- pass A: dQ
+    for (int qt = 0; qt < n_t; ++qt) {
+        const int q_row = qt * 16 + c;
+        const pmx_bf16x8 qf = row8(base, row_stride, head_off, q_row);
+        const pmx_bf16x8 dof = row8(dobase, orow, ohead, q_row);
+        const float ls = lse_s[q_row < S_pad ? q_row : 0], dl = delta_s[q_row < S_pad ? q_row : 0];
+        pmx_f32x4 dq = z4;
+        for (int kp = 0; kp < n_p; ++kp) {
+            const pmx_bf16x8 k0 = row8(base, row_stride, head_off + E, kp * 32 + c), k1 = row8(base, row_stride, head_off + E, kp * 32 + 16 + c);
+            const pmx_bf16x8 v0 = row8(base, row_stride, head_off + 2 * E, kp * 32 + c), v1 = row8(base, row_stride, head_off + 2 * E, kp * 32 + 16 + c);
+            const pmx_f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf, z4, 0, 0, 0);
+            const pmx_f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf, z4, 0, 0, 0);
+            const pmx_f32x4 p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, dof, z4, 0, 0, 0);
+            const pmx_f32x4 p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, dof, z4, 0, 0, 0);
+            pmx_bf16x8 dsf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key0 = kp * 32 + g * 4 + r, key1 = key0 + 16;
+                const float e0 = key0 < S ? __expf(s0[r] * scale - ls) : 0.f;
+                const float e1 = key1 < S ? __expf(s1[r] * scale - ls) : 0.f;
+                dsf[r] = pmx_f2bf(e0 * (p0[r] - dl));
+                dsf[4 + r] = pmx_f2bf(e1 * (p1[r] - dl));
+            }
+            dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Kt, kp), dsf, dq, 0, 0, 0);
+        }
+        if (q_row < S && g < 2) {
+            short w4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w4[r] = pmx_f2bf(dq[r] * scale);
+            *reinterpret_cast<uint2 *>(dbase + (size_t)q_row * row_stride + head_off + g * 4) = *reinterpret_cast<const uint2 *>(w4);
+        }
+    }
+    // ---- pass B: dK, dV
+    for (int kt = 0; kt < n_t; ++kt) {
+        const int k_row = kt * 16 + c;
+        const pmx_bf16x8 kf = row8(base, row_stride, head_off + E, k_row);
+        const pmx_bf16x8 vf = row8(base, row_stride, head_off + 2 * E, k_row);
+        pmx_f32x4 dk = z4, dv = z4;
+        for (int qp = 0; qp < n_p; ++qp) {
+            const pmx_bf16x8 q0 = row8(base, row_stride, head_off, qp * 32 + c), q1 = row8(base, row_stride, head_off, qp * 32 + 16 + c);
+            const pmx_bf16x8 d0 = row8(dobase, orow, ohead, qp * 32 + c), d1 = row8(dobase, orow, ohead, qp * 32 + 16 + c);
+            // S = Q . K^T: rows = queries (4g + r), column = key c
+            const pmx_f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, kf, z4, 0, 0, 0);
+            const pmx_f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, kf, z4, 0, 0, 0);
+            const pmx_f32x4 p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0, vf, z4, 0, 0, 0);
+            const pmx_f32x4 p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1, vf, z4, 0, 0, 0);
+            pmx_bf16x8 pf, dsf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qa = qp * 32 + g * 4 + r, qb = qa + 16;
+                const float e0 = k_row < S ? __expf(s0[r] * scale - lse_s[qa]) : 0.f;      // padded queries carry lse = 1e30
+                const float e1 = k_row < S ? __expf(s1[r] * scale - lse_s[qb]) : 0.f;
+                pf[r] = pmx_f2bf(e0); pf[4 + r] = pmx_f2bf(e1);
+                dsf[r] = pmx_f2bf(e0 * (p0[r] - delta_s[qa]));
+                dsf[4 + r] = pmx_f2bf(e1 * (p1[r] - delta_s[qb]));
+            }
+            dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(dOt, qp), pf, dv, 0, 0, 0);
+            dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Qt, qp), dsf, dk, 0, 0, 0);
+        }
+        if (k_row < S && g < 2) {
+            short wk[4], wv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { wk[r] = pmx_f2bf(dk[r] * scale); wv[r] = pmx_f2bf(dv[r]); }
+            *reinterpret_cast<uint2 *>(dbase + (size_t)k_row * row_stride + head_off + E + g * 4) = *reinterpret_cast<const uint2 *>(wk);
+            *reinterpret_cast<uint2 *>(dbase + (size_t)k_row * row_stride + head_off + 2 * E + g * 4) = *reinterpret_cast<const uint2 *>(wv);
+        }
+    }
+}
+
+// dqkv_dev [S][B][96] bf16 is written in full.  S <= 640 (LDS: 56 * S_pad bytes per wavefront).
+extern "C" int pmx_attn8_backward(const void *qkv_dev, const void *out_dev, const void *dout_dev, const float *lse_dev, void *dqkv_dev,
+                                  int32_t S, int32_t B, void *stream)
+{
+    if (!qkv_dev || !out_dev || !dout_dev || !lse_dev || !dqkv_dev || S < 1 || S > 640 || B < 0) return PMX_ERR_INVALID;
+    if (B == 0) return PMX_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int S_pad = (S + 31) & ~31;
+    const size_t lds = (size_t)4 * ((size_t)3 * 8 * S_pad * sizeof(short) + (size_t)2 * S_pad * sizeof(float));
+    static bool attr_set = false;
+    if (lds > 65536 && !attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(pmx_attn8_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return PMX_ERR_HIP;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(pmx_attn8_bwd_kernel, dim3(B), dim3(256), lds, st, (const __hip_bfloat16 *)qkv_dev, (const __hip_bfloat16 *)out_dev,
+                       (const __hip_bfloat16 *)dout_dev, lse_dev, (__hip_bfloat16 *)dqkv_dev, S, B, 0.35355339059327379f);
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}

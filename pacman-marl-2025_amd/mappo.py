@@ -94,6 +94,34 @@ def attention8_forward(qkv, want_lse=False):
     return (out, lse) if want_lse else out
 
 
+class _Attention8(torch.autograd.Function):
+    """Differentiable wrapper of the MFMA attention kernels (pmx_attn8_forward / pmx_attn8_backward)."""
+
+    @staticmethod
+    def forward(ctx, qkv):
+        out, lse = attention8_forward(qkv, want_lse=True)
+        ctx.save_for_backward(qkv.contiguous(), out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        qkv, out, lse = ctx.saved_tensors
+        S, B, _ = qkv.shape
+        gout = gout.contiguous().to(torch.bfloat16)
+        dqkv = torch.empty_like(qkv)
+        st = C.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)
+        _lib.check(lib.pmx_attn8_backward(qkv.data_ptr(), out.data_ptr(), gout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), S, B, st),
+                   "pmx_attn8_backward")
+        return dqkv
+
+
+def attention8(qkv):
+    return _Attention8.apply(qkv)
+
+
 class _TokenLinear(torch.autograd.Function):
     """F.linear on a token tensor [S, B, in] with the weight gradient computed as S batched GEMMs of depth B followed by
     a sum over S.  hipBLASLt's choice for the flat [S*B, in]^T x [S*B, out] product (K = 630 k rows, a 32 x 128 result)
@@ -134,8 +162,8 @@ class CriticEncoderLayer(nn.TransformerEncoderLayer):
         mha = self.self_attn
         h, d = mha.num_heads, E // mha.num_heads
         qkv = token_linear(x, mha.in_proj_weight, mha.in_proj_bias)
-        if (not torch.is_grad_enabled()) and qkv.is_cuda and qkv.dtype == torch.bfloat16 and E == 32 and h == 4 and S <= 1024:
-            a = attention8_forward(qkv)                                # inference: hand-written MFMA attention
+        if qkv.is_cuda and qkv.dtype == torch.bfloat16 and E == 32 and h == 4 and S <= (640 if torch.is_grad_enabled() else 1024):
+            a = attention8(qkv) if torch.is_grad_enabled() else attention8_forward(qkv)   # hand-written MFMA attention
             a = token_linear(a, mha.out_proj.weight, mha.out_proj.bias)
             x = add_layer_norm_small(x, a, self.norm1)
             f = token_linear(F.relu(token_linear(x, self.linear1.weight, self.linear1.bias)), self.linear2.weight, self.linear2.bias)

@@ -204,3 +204,24 @@ def test_mfma_attention_forward_matches_torch(S, B):
     err = float((out.float() - ref).abs().max())
     assert err <= 2e-2 * (float(ref.abs().max()) + 1e-6), err                          # bf16 probabilities / outputs
     assert float((lse - torch.logsumexp(sc, -1)).abs().max()) <= 2e-3
+
+
+@pytest.mark.parametrize("S,B", [(154, 19), (140, 5), (400, 4), (33, 3), (640, 2)])
+def test_mfma_attention_backward_matches_torch(S, B):
+    """pmx_attn8_backward against torch autograd of softmax(q k^T / sqrt(8)) v in float32 on the same bf16 inputs."""
+    from pmx import mappo
+    torch.manual_seed(S + 1)
+    qkv = (torch.randn(S, B, 96, device="cuda") * 1.3).to(torch.bfloat16).requires_grad_(True)
+    g = torch.randn(S, B, 32, device="cuda").to(torch.bfloat16)
+    out = mappo.attention8(qkv)
+    out.backward(g)
+    got = qkv.grad.float()
+    x = qkv.detach().float().requires_grad_(True)
+    q, k, v = x.chunk(3, dim=-1)
+    q, k, v = (t.reshape(S, B, 4, 8).permute(1, 2, 0, 3) for t in (q, k, v))
+    ref_out = torch.matmul(torch.softmax(torch.matmul(q, k.transpose(-1, -2)) / 8 ** 0.5, -1), v).permute(2, 0, 1, 3).reshape(S, B, 32)
+    ref_out.backward(g.float())
+    ref = x.grad
+    for name, sl in (("dq", slice(0, 32)), ("dk", slice(32, 64)), ("dv", slice(64, 96))):
+        err = float((got[..., sl] - ref[..., sl]).abs().max())
+        assert err <= 3e-2 * (float(ref[..., sl].abs().max()) + 1e-6), (name, err, float(ref[..., sl].abs().max()))
