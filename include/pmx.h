@@ -202,6 +202,13 @@ int pmx_gn8_gelu_backward(const void *h_dev, const void *res_dev, const void *dy
                           const float *mean_dev, const float *rstd_dev, void *dh_dev, void *dres_dev, float *partial_dev, int64_t B,
                           int32_t groups, int32_t HW, int32_t dtype, void *stream);
 
+/* The same for channels-last bfloat16 tensors ([B][H*W][groups*8] in memory: what MIOpen's NHWC convolutions read and write). */
+int pmx_gn8cl_gelu_forward(const void *h_dev, const void *res_dev, const float *w_dev, const float *b_dev, void *y_dev, float *mean_dev,
+                           float *rstd_dev, int64_t B, int32_t groups, int32_t HW, float eps, void *stream);
+int pmx_gn8cl_gelu_backward(const void *h_dev, const void *res_dev, const void *dy_dev, const float *w_dev, const float *b_dev,
+                            const float *mean_dev, const float *rstd_dev, void *dh_dev, void *dres_dev, float *partial_dev, int64_t B,
+                            int32_t groups, int32_t HW, void *stream);
+
 /* Self-attention forward of the critic's encoder layers (nn.MultiheadAttention, embed 32, 4 heads of 8,
  * pacman_mappo_resnet.py:138-141) on the matrix cores: qkv_dev [S][B][96] bfloat16 = packed in-projection output,
  * out_dev [S][B][32] bfloat16 = concatenated heads before the out-projection, lse_dev [B][4][S] float32 (may be NULL).

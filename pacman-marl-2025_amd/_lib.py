@@ -62,6 +62,8 @@ PROTOTYPES = [
     ("pmx_ln32_backward", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _I32, _VP]),
     ("pmx_gn8_gelu_forward", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _I32, _I32, C.c_float, _I32, _VP]),
     ("pmx_gn8_gelu_backward", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _I32, _I32, _I32, _VP]),
+    ("pmx_gn8cl_gelu_forward", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _I32, _I32, C.c_float, _VP]),
+    ("pmx_gn8cl_gelu_backward", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _I32, _I32, _VP]),
     ("pmx_attn8_forward", C.c_int, [_VP, _VP, _VP, _I32, _I32, _VP]),
     ("pmx_attn8_backward", C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _VP]),
     ("pmx_canonicalize_obs", C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _VP]),

@@ -852,3 +852,179 @@ extern "C" int pmx_attn8_backward(const void *qkv_dev, const void *out_dev, cons
                        (const __hip_bfloat16 *)dout_dev, lse_dev, (__hip_bfloat16 *)dqkv_dev, S, B, 0.35355339059327379f);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same fused GroupNorm(8 ch/group) + residual + GELU for channels-last tensors ([B][H*W][C] in memory, what
+// MIOpen's NHWC implicit-GEMM convolutions produce and consume): the 8 channels of a group at one position are 16
+// contiguous bytes of bf16, so a lane owns whole positions (lane + 64 k) and every access is one 16-byte load / store.
+// Running the actor channels-last end to end removes the NCHW<->NHWC transposes around every convolution.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cl_load8(const __hip_bfloat16 *p, float *v)
+{
+    const uint4 t = *reinterpret_cast<const uint4 *>(p);
+    const uint32_t w[4] = { t.x, t.y, t.z, t.w };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u); }
+}
+__device__ __forceinline__ void cl_store8(__hip_bfloat16 *p, const float *v)
+{
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = (uint32_t)(uint16_t)pmx_f2bf(v[2 * j]) | ((uint32_t)(uint16_t)pmx_f2bf(v[2 * j + 1]) << 16);
+    *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void pmx_gn8cl_gelu_fwd_kernel(const __hip_bfloat16 *__restrict__ h, const __hip_bfloat16 *__restrict__ res,
+                                                                 const float *__restrict__ w, const float *__restrict__ b,
+                                                                 __hip_bfloat16 *__restrict__ y, float *__restrict__ mean_out,
+                                                                 float *__restrict__ rstd_out, long rows, int groups, int HW, float eps)
+{
+    constexpr int CPG = 8;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int g = (int)(row % groups);
+    const long n = row / groups;
+    const int C = groups * CPG;
+    const size_t base = (size_t)n * HW * C + (size_t)g * CPG;       // + pos * C
+    float v[KMAX][CPG];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int pos = lane + 64 * k;
+        if (pos < HW) cl_load8(h + base + (size_t)pos * C, v[k]);
+        else {
+#pragma unroll
+            for (int c = 0; c < CPG; ++c) v[k][c] = 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < CPG; ++c) s += v[k][c];
+    }
+    const float inv = 1.0f / (float)(CPG * HW);
+    const float mean = wave_sum(s) * inv;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (lane + 64 * k < HW) {
+#pragma unroll
+            for (int c = 0; c < CPG; ++c) { const float d = v[k][c] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) * inv + eps);
+    float wc[CPG], bc[CPG];
+#pragma unroll
+    for (int c = 0; c < CPG; ++c) { wc[c] = w[g * CPG + c] * rstd; bc[c] = b[g * CPG + c]; }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int pos = lane + 64 * k;
+        if (pos < HW) {
+            float r8[CPG], o8[CPG];
+            if (res) cl_load8(res + base + (size_t)pos * C, r8);
+#pragma unroll
+            for (int c = 0; c < CPG; ++c) {
+                float z = (v[k][c] - mean) * wc[c] + bc[c];
+                if (res) z += r8[c];
+                o8[c] = gelu_f(z);
+            }
+            cl_store8(y + base + (size_t)pos * C, o8);
+        }
+    }
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void pmx_gn8cl_gelu_bwd_kernel(const __hip_bfloat16 *__restrict__ h, const __hip_bfloat16 *__restrict__ res,
+                                                                 const __hip_bfloat16 *__restrict__ dy, const float *__restrict__ w,
+                                                                 const float *__restrict__ b, const float *__restrict__ mean_in,
+                                                                 const float *__restrict__ rstd_in, __hip_bfloat16 *__restrict__ dh,
+                                                                 __hip_bfloat16 *__restrict__ dres, float *__restrict__ partial, long rows,
+                                                                 int groups, int HW)
+{
+    constexpr int CPG = 8;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int g = (int)(row % groups);
+    const long n = row / groups;
+    const int C = groups * CPG;
+    const size_t base = (size_t)n * HW * C + (size_t)g * CPG;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float wc[CPG], bc[CPG], sw[CPG], sb[CPG];
+#pragma unroll
+    for (int c = 0; c < CPG; ++c) { wc[c] = w[g * CPG + c]; bc[c] = b[g * CPG + c]; sw[c] = 0.f; sb[c] = 0.f; }
+    float xh[KMAX][CPG], gz[KMAX][CPG];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int pos = lane + 64 * k;
+#pragma unroll
+        for (int c = 0; c < CPG; ++c) { xh[k][c] = 0.f; gz[k][c] = 0.f; }
+        if (pos < HW) {
+            float h8[CPG], r8[CPG], d8[CPG], dz8[CPG];
+            cl_load8(h + base + (size_t)pos * C, h8);
+            cl_load8(dy + base + (size_t)pos * C, d8);
+            if (res) cl_load8(res + base + (size_t)pos * C, r8);
+#pragma unroll
+            for (int c = 0; c < CPG; ++c) {
+                const float x = (h8[c] - mean) * rstd;
+                float z = x * wc[c] + bc[c];
+                if (res) z += r8[c];
+                const float dz = d8[c] * gelu_grad_f(z);
+                dz8[c] = dz;
+                sw[c] += dz * x; sb[c] += dz;
+                const float gg = dz * wc[c];
+                xh[k][c] = x; gz[k][c] = gg;
+                c1 += gg; c2 += gg * x;
+            }
+            if (dres) cl_store8(dres + base + (size_t)pos * C, dz8);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CPG; ++c) {
+        const float a = wave_sum(sw[c]), bb = wave_sum(sb[c]);
+        if (lane == 0) { partial[((size_t)row * CPG + c) * 2] = a; partial[((size_t)row * CPG + c) * 2 + 1] = bb; }
+    }
+    const float inv = 1.0f / (float)(CPG * HW);
+    c1 = wave_sum(c1) * inv; c2 = wave_sum(c2) * inv;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int pos = lane + 64 * k;
+        if (pos < HW) {
+            float o8[CPG];
+#pragma unroll
+            for (int c = 0; c < CPG; ++c) o8[c] = rstd * (gz[k][c] - c1 - xh[k][c] * c2);
+            cl_store8(dh + base + (size_t)pos * C, o8);
+        }
+    }
+}
+
+// channels-last (bfloat16 only): tensors are [B][H*W][groups*8] in memory
+extern "C" int pmx_gn8cl_gelu_forward(const void *h, const void *res, const float *w, const float *b, void *y, float *mean, float *rstd,
+                                      int64_t B, int32_t groups, int32_t HW, float eps, void *stream)
+{
+    if (!h || !w || !b || !y || !mean || !rstd || B < 0 || groups < 1 || HW < 1 || HW > 1024) return PMX_ERR_INVALID;
+    const long rows = (long)B * groups;
+    if (rows == 0) return PMX_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+#define PMX_GNCL_FWD(K) hipLaunchKernelGGL((pmx_gn8cl_gelu_fwd_kernel<K>), dim3(grid), dim3(256), 0, st, (const __hip_bfloat16 *)h, (const __hip_bfloat16 *)res, w, b, (__hip_bfloat16 *)y, mean, rstd, rows, groups, HW, eps)
+    if (HW <= 192) PMX_GNCL_FWD(3); else if (HW <= 448) PMX_GNCL_FWD(7); else PMX_GNCL_FWD(16);
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
+
+extern "C" int pmx_gn8cl_gelu_backward(const void *h, const void *res, const void *dy, const float *w, const float *b, const float *mean,
+                                       const float *rstd, void *dh, void *dres, float *partial, int64_t B, int32_t groups, int32_t HW,
+                                       void *stream)
+{
+    if (!h || !dy || !w || !b || !mean || !rstd || !dh || !partial || B < 0 || groups < 1 || HW < 1 || HW > 1024) return PMX_ERR_INVALID;
+    if ((res == nullptr) != (dres == nullptr)) return PMX_ERR_INVALID;
+    const long rows = (long)B * groups;
+    if (rows == 0) return PMX_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+#define PMX_GNCL_BWD(K) hipLaunchKernelGGL((pmx_gn8cl_gelu_bwd_kernel<K>), dim3(grid), dim3(256), 0, st, (const __hip_bfloat16 *)h, (const __hip_bfloat16 *)res, (const __hip_bfloat16 *)dy, w, b, mean, rstd, (__hip_bfloat16 *)dh, (__hip_bfloat16 *)dres, partial, rows, groups, HW)
+    if (HW <= 192) PMX_GNCL_BWD(3); else if (HW <= 448) PMX_GNCL_BWD(7); else PMX_GNCL_BWD(16);
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}

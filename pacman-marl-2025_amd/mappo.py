@@ -186,8 +186,11 @@ class _GN8Gelu(torch.autograd.Function):
         import ctypes as C
         from . import _lib
         lib = _lib.load()
-        h = h.contiguous()
-        res = res.contiguous() if res is not None else None
+        # channels-last bf16 tensors (what MIOpen's NHWC convolutions produce) take the NHWC kernels, anything else NCHW
+        cl = h.dtype == torch.bfloat16 and h.is_contiguous(memory_format=torch.channels_last) and not h.is_contiguous()
+        fmt = torch.channels_last if cl else torch.contiguous_format
+        h = h.contiguous(memory_format=fmt)
+        res = res.contiguous(memory_format=fmt) if res is not None else None
         B, Cc = h.shape[0], h.shape[1]
         HW = h.numel() // (B * Cc)
         y = torch.empty_like(h)
@@ -195,11 +198,16 @@ class _GN8Gelu(torch.autograd.Function):
         rstd = torch.empty(B * groups, dtype=torch.float32, device=h.device)
         wf, bf = w.float().contiguous(), b.float().contiguous()
         st = C.c_void_p(torch.cuda.current_stream(h.device).cuda_stream)
-        _lib.check(lib.pmx_gn8_gelu_forward(h.data_ptr(), res.data_ptr() if res is not None else None, wf.data_ptr(), bf.data_ptr(),
-                                            y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, groups, HW, float(eps),
-                                            0 if h.dtype == torch.float32 else 1, st), "pmx_gn8_gelu_forward")
+        rp = res.data_ptr() if res is not None else None
+        if cl:
+            _lib.check(lib.pmx_gn8cl_gelu_forward(h.data_ptr(), rp, wf.data_ptr(), bf.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                                  rstd.data_ptr(), B, groups, HW, float(eps), st), "pmx_gn8cl_gelu_forward")
+        else:
+            _lib.check(lib.pmx_gn8_gelu_forward(h.data_ptr(), rp, wf.data_ptr(), bf.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                                rstd.data_ptr(), B, groups, HW, float(eps), 0 if h.dtype == torch.float32 else 1, st),
+                       "pmx_gn8_gelu_forward")
         ctx.save_for_backward(h, res if res is not None else h.new_empty(0), wf, bf, mean, rstd)
-        ctx.has_res, ctx.groups, ctx.HW = res is not None, groups, HW
+        ctx.has_res, ctx.groups, ctx.HW, ctx.cl = res is not None, groups, HW, cl
         return y
 
     @staticmethod
@@ -208,16 +216,21 @@ class _GN8Gelu(torch.autograd.Function):
         from . import _lib
         lib = _lib.load()
         h, res, wf, bf, mean, rstd = ctx.saved_tensors
-        gy = gy.contiguous()
+        gy = gy.contiguous(memory_format=torch.channels_last if ctx.cl else torch.contiguous_format)
         B, Cc = h.shape[0], h.shape[1]
         dh = torch.empty_like(h)
         dres = torch.empty_like(h) if ctx.has_res else None
         partial = torch.empty(B, Cc, 2, dtype=torch.float32, device=h.device)
         st = C.c_void_p(torch.cuda.current_stream(h.device).cuda_stream)
-        _lib.check(lib.pmx_gn8_gelu_backward(h.data_ptr(), res.data_ptr() if ctx.has_res else None, gy.data_ptr(), wf.data_ptr(),
-                                             bf.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dh.data_ptr(),
-                                             dres.data_ptr() if ctx.has_res else None, partial.data_ptr(), B, ctx.groups, ctx.HW,
-                                             0 if h.dtype == torch.float32 else 1, st), "pmx_gn8_gelu_backward")
+        rp, dp = (res.data_ptr(), dres.data_ptr()) if ctx.has_res else (None, None)
+        if ctx.cl:
+            _lib.check(lib.pmx_gn8cl_gelu_backward(h.data_ptr(), rp, gy.data_ptr(), wf.data_ptr(), bf.data_ptr(), mean.data_ptr(),
+                                                   rstd.data_ptr(), dh.data_ptr(), dp, partial.data_ptr(), B, ctx.groups, ctx.HW, st),
+                       "pmx_gn8cl_gelu_backward")
+        else:
+            _lib.check(lib.pmx_gn8_gelu_backward(h.data_ptr(), rp, gy.data_ptr(), wf.data_ptr(), bf.data_ptr(), mean.data_ptr(),
+                                                 rstd.data_ptr(), dh.data_ptr(), dp, partial.data_ptr(), B, ctx.groups, ctx.HW,
+                                                 0 if h.dtype == torch.float32 else 1, st), "pmx_gn8_gelu_backward")
         g = partial.sum(0)
         return dh, dres, g[:, 0], g[:, 1], None, None
 
@@ -303,6 +316,10 @@ class MAPPOAgent(nn.Module):
                 m.bias.data.fill_(0.0)
 
     def logits(self, obs):
+        if obs.is_cuda and obs.dtype == torch.bfloat16 and obs.dim() == 4:
+            # channels-last end to end: MIOpen's NHWC bf16 implicit-GEMM convolutions and the NHWC GroupNorm kernels then
+            # need no layout transposes; nn.Flatten still flattens in logical (C, H, W) order, one copy at the end
+            obs = obs.contiguous(memory_format=torch.channels_last)
         return self.actor_head(self.actor_backbone(obs))
 
     def value(self, merged_obs):

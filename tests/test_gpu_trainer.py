@@ -159,8 +159,11 @@ def test_fused_add_layernorm32_matches_torch(dtype, tol):
         assert float((u - v).abs().max()) <= tol * scale * (8 if name in ("dw", "db") and dtype == torch.bfloat16 else 1), name
 
 
-@pytest.mark.parametrize("dtype,tol,hw", [(torch.float32, 3e-5, (11, 14)), (torch.bfloat16, 3e-2, (11, 14)), (torch.float32, 3e-5, (20, 20)), (torch.float32, 3e-5, (32, 32))])
-def test_fused_groupnorm_gelu_matches_torch(dtype, tol, hw):
+@pytest.mark.parametrize("dtype,tol,hw,cl", [(torch.float32, 3e-5, (11, 14), False), (torch.bfloat16, 3e-2, (11, 14), False),
+                                              (torch.float32, 3e-5, (20, 20), False), (torch.float32, 3e-5, (32, 32), False),
+                                              (torch.bfloat16, 3e-2, (11, 14), True), (torch.bfloat16, 3e-2, (20, 20), True),
+                                              (torch.bfloat16, 3e-2, (32, 32), True)])
+def test_fused_groupnorm_gelu_matches_torch(dtype, tol, hw, cl):
     """pmx_gn8_gelu_forward/backward against gelu(group_norm(h) + res) computed by torch in float32, with and without residual."""
     from pmx import mappo
     torch.manual_seed(1)
@@ -169,9 +172,10 @@ def test_fused_groupnorm_gelu_matches_torch(dtype, tol, hw):
     with torch.no_grad():
         gn.weight.copy_(torch.randn(C).cuda() * 0.3 + 1.0); gn.bias.copy_(torch.randn(C).cuda() * 0.2)
     for with_res in (False, True):
-        h = (torch.randn(B, C, *hw, device="cuda") * 1.5 + 0.3).to(dtype).requires_grad_(True)
-        r = torch.randn(B, C, *hw, device="cuda").to(dtype).requires_grad_(True) if with_res else None
-        g = torch.randn(B, C, *hw, device="cuda").to(dtype)
+        fmt = torch.channels_last if cl else torch.contiguous_format
+        h = (torch.randn(B, C, *hw, device="cuda") * 1.5 + 0.3).to(dtype).contiguous(memory_format=fmt).requires_grad_(True)
+        r = torch.randn(B, C, *hw, device="cuda").to(dtype).contiguous(memory_format=fmt).requires_grad_(True) if with_res else None
+        g = torch.randn(B, C, *hw, device="cuda").to(dtype).contiguous(memory_format=fmt)
         gn.zero_grad()
         y = mappo.group_norm_gelu(h, r, gn)
         y.backward(g)
