@@ -564,21 +564,21 @@ __device__ __forceinline__ short pmx_f2bf(float f)
     return *reinterpret_cast<const short *>(&h);
 }
 
-__global__ __launch_bounds__(256) void pmx_attn8_fwd_kernel(const __hip_bfloat16 *__restrict__ qkv, __hip_bfloat16 *__restrict__ out,
+__global__ __launch_bounds__(512) void pmx_attn8_fwd_kernel(const __hip_bfloat16 *__restrict__ qkv, __hip_bfloat16 *__restrict__ out,
                                                             float *__restrict__ lse, int S, int B, float scale)
 {
     constexpr int D = 8, HEADS = 4, E = 32;
     extern __shared__ __align__(16) unsigned char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = blockIdx.x, h = wave;
+    const int b = blockIdx.x, h = wave & 3, role = wave >> 2;        // two wavefronts per head: they split the query tiles
     const int S_pad = (S + 31) & ~31;
-    // per wave: K [S_pad][8] bf16, then V^T [8][S_pad] bf16
-    short *Ks = reinterpret_cast<short *>(smem) + (size_t)wave * 2 * S_pad * D;
+    // per head: K [S_pad][8] bf16, then V^T [8][S_pad] bf16
+    short *Ks = reinterpret_cast<short *>(smem) + (size_t)h * 2 * S_pad * D;
     short *Vt = Ks + (size_t)S_pad * D;
     const short *base = reinterpret_cast<const short *>(qkv);
     const size_t row_stride = (size_t)B * 3 * E;                     // elements between consecutive sequence positions
     const size_t head_off = (size_t)b * 3 * E + (size_t)h * D;
-    for (int s = lane; s < S_pad; s += 64) {
+    for (int s = lane + 64 * role; s < S_pad; s += 128) {
         uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
         if (s < S) {
             kv = *reinterpret_cast<const uint4 *>(base + (size_t)s * row_stride + head_off + E);
@@ -589,13 +589,12 @@ __global__ __launch_bounds__(256) void pmx_attn8_fwd_kernel(const __hip_bfloat16
 #pragma unroll
         for (int d = 0; d < D; ++d) Vt[(size_t)d * S_pad + s] = vs[d];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
 
     const int g = lane >> 4, c = lane & 15;
     const pmx_bf16x8 zero8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
     const int n_qt = (S + 15) >> 4, n_kp = S_pad >> 5;
-    for (int qt = 0; qt < n_qt; ++qt) {
+    for (int qt = role; qt < n_qt; qt += 2) {
         const int q_row = qt * 16 + c;
         pmx_bf16x8 qf = zero8;
         if (g == 0 && q_row < S) qf = *reinterpret_cast<const pmx_bf16x8 *>(base + (size_t)q_row * row_stride + head_off);
@@ -678,7 +677,7 @@ extern "C" int pmx_attn8_forward(const void *qkv_dev, void *out_dev, float *lse_
             return PMX_ERR_HIP;
         attr_set = true;
     }
-    hipLaunchKernelGGL(pmx_attn8_fwd_kernel, dim3(B), dim3(256), lds, st, (const __hip_bfloat16 *)qkv_dev, (__hip_bfloat16 *)out_dev, lse_dev, S, B,
+    hipLaunchKernelGGL(pmx_attn8_fwd_kernel, dim3(B), dim3(512), lds, st, (const __hip_bfloat16 *)qkv_dev, (__hip_bfloat16 *)out_dev, lse_dev, S, B,
                        0.35355339059327379f /* 1/sqrt(8) */);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
@@ -695,17 +694,17 @@ extern "C" int pmx_attn8_forward(const void *qkv_dev, void *out_dev, float *lse_
 // the row-major operands of the score products are read straight from global memory (16 bytes per lane, L1-resident).
 // Gradients are written in the packed [S][B][96] layout of the in-projection output.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pmx_attn8_bwd_kernel(const __hip_bfloat16 *__restrict__ qkv, const __hip_bfloat16 *__restrict__ outp,
+__global__ __launch_bounds__(512) void pmx_attn8_bwd_kernel(const __hip_bfloat16 *__restrict__ qkv, const __hip_bfloat16 *__restrict__ outp,
                                                             const __hip_bfloat16 *__restrict__ dout, const float *__restrict__ lse,
                                                             __hip_bfloat16 *__restrict__ dqkv, int S, int B, float scale)
 {
     constexpr int D = 8, HEADS = 4, E = 32;
     extern __shared__ __align__(16) unsigned char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = blockIdx.x, h = wave;
+    const int b = blockIdx.x, h = wave & 3, role = wave >> 2;        // two wavefronts per head: role 0 = dQ pass, role 1 = dK/dV pass
     const int S_pad = (S + 31) & ~31;
     const size_t per_wave = (size_t)3 * D * S_pad * sizeof(short) + (size_t)2 * S_pad * sizeof(float);
-    unsigned char *mine = smem + (size_t)wave * per_wave;
+    unsigned char *mine = smem + (size_t)h * per_wave;
     short *Kt = reinterpret_cast<short *>(mine);                    // [8][S_pad]
     short *Qt = Kt + (size_t)D * S_pad;
     short *dOt = Qt + (size_t)D * S_pad;
@@ -717,7 +716,7 @@ __global__ __launch_bounds__(256) void pmx_attn8_bwd_kernel(const __hip_bfloat16
     const size_t row_stride = (size_t)B * 3 * E, orow = (size_t)B * E;
     const size_t head_off = (size_t)b * 3 * E + (size_t)h * D, ohead = (size_t)b * E + (size_t)h * D;
 
-    for (int s = lane; s < S_pad; s += 64) {
+    for (int s = lane + 64 * role; s < S_pad; s += 128) {
         uint4 qv = make_uint4(0, 0, 0, 0), kv = qv, dov = qv, ov = qv;
         float ls = 1e30f;                                            // padded queries: exp(score - 1e30) = 0
         if (s < S) {
@@ -739,8 +738,7 @@ __global__ __launch_bounds__(256) void pmx_attn8_bwd_kernel(const __hip_bfloat16
         }
         lse_s[s] = ls; delta_s[s] = delta;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
 
     const int g = lane >> 4, c = lane & 15;
     const pmx_bf16x8 zero8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -765,6 +763,7 @@ __global__ __launch_bounds__(256) void pmx_attn8_bwd_kernel(const __hip_bfloat16
     };
 
     // ---- pass A: dQ
+    if (role == 0)
     for (int qt = 0; qt < n_t; ++qt) {
         const int q_row = qt * 16 + c;
         const pmx_bf16x8 qf = row8(base, row_stride, head_off, q_row);
@@ -797,6 +796,7 @@ __global__ __launch_bounds__(256) void pmx_attn8_bwd_kernel(const __hip_bfloat16
         }
     }
     // ---- pass B: dK, dV
+    if (role == 1)
     for (int kt = 0; kt < n_t; ++kt) {
         const int k_row = kt * 16 + c;
         const pmx_bf16x8 kf = row8(base, row_stride, head_off + E, k_row);
@@ -848,7 +848,7 @@ extern "C" int pmx_attn8_backward(const void *qkv_dev, const void *out_dev, cons
             return PMX_ERR_HIP;
         attr_set = true;
     }
-    hipLaunchKernelGGL(pmx_attn8_bwd_kernel, dim3(B), dim3(256), lds, st, (const __hip_bfloat16 *)qkv_dev, (const __hip_bfloat16 *)out_dev,
+    hipLaunchKernelGGL(pmx_attn8_bwd_kernel, dim3(B), dim3(512), lds, st, (const __hip_bfloat16 *)qkv_dev, (const __hip_bfloat16 *)out_dev,
                        (const __hip_bfloat16 *)dout_dev, lse_dev, (__hip_bfloat16 *)dqkv_dev, S, B, 0.35355339059327379f);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
