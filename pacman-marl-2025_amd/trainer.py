@@ -106,6 +106,8 @@ class VecMAPPOTrainer:
         # Optional: replay the optimizer step from a hipGraph when every minibatch has the same shape.  Off by default: with
         # bf16 autocast the replayed step intermittently produced a non-finite gradient norm on some boxes (never in
         # fp32, never eagerly; root cause not found yet -- DESIGN.md section 5), and a training loop must not be flaky.
+        if use_graph and use_autocast:
+            raise ValueError("hipGraph replay of the optimizer step is only supported without bf16 autocast (see DESIGN.md section 5)")
         self.use_graph = bool(use_graph) and (horizon * n_envs * 2) % minibatch == 0
         self._graph_ready = False
 
