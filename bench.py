@@ -98,7 +98,8 @@ def ppo_probe(layname, dev):
     tr.env.close()
     return {"optimizer_steps_per_s": steps / t_upd, "samples_per_optimizer_step": mb, "train_samples_per_s": steps * mb / t_upd,
             "rollout_env_steps_per_s": n_envs * horizon / t_roll, "rollout_envs": n_envs, "horizon": horizon,
-            "network": "MAPPOAgent (ResNet actor + transformer critic), bf16 autocast, PyTorch-ROCm ops + fused HIP add+LayerNorm",
+            "network": "MAPPOAgent (ResNet actor + transformer critic), bf16 autocast; MIOpen NHWC convolutions + hipBLASLt + hand-written "
+                       "HIP attention (MFMA), add+LayerNorm and GroupNorm+GELU kernels",
             "reference_cpu": "about 0.5 optimizer-steps/s and 25 env-steps/s end to end on 8 host cores (SURVEY section 6)"}
 
 

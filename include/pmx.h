@@ -49,6 +49,14 @@ enum { PMX_OBS_F32 = 0, PMX_OBS_BF16 = 1, PMX_OBS_U8 = 2 };
  * distribution-equivalent to the reference's (which uses Python's global Mersenne Twister) and is reproduced exactly
  * by the test oracle. */
 #define PMX_ACTION_RANDOM_LEGAL (-2)
+/* In-kernel baselineTeam opponents (agents/baselineTeam.py:65-187): the env scores the successor of every legal action of
+ * the agent on the mid-tick state with the reference's reflex features and weights (offensive: -100 * food left - maze
+ * distance to the nearest pellet; defensive: invaders, on-defence, invader distance, stop, reverse) and plays one of the
+ * best actions (tie-break by the counter-based generator instead of random.choice); with no food left the agent walks home.
+ * Needs the layouts' maze-distance matrices resident on the device (kept when they total <= 2 GiB; otherwise the codes
+ * act as Stop). */
+#define PMX_ACTION_BASELINE_OFFENSE (-3)
+#define PMX_ACTION_BASELINE_DEFENSE (-4)
 
 typedef struct pmx_env pmx_env;
 

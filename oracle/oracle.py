@@ -227,6 +227,28 @@ class MultiBatchEnv:
                                       self.agent.ctypes)
 
 
+def bot_tables(rows):
+    """(dist [n,n] uint8, cell_index int16[32*32], n) for the in-kernel baselineTeam action codes."""
+    cells, dist = maze_distances(rows)
+    idx = np.full(MAXD * MAXD, -1, np.int16)
+    for k, (x, y) in enumerate(cells):
+        idx[int(y) * MAXD + int(x)] = k
+    return np.ascontiguousarray(dist), idx, len(cells)
+
+
+def bot_best(env, agent, defensive, tables):
+    """-> (bit mask of the best actions, home action or -1) for the reflex bot of `agent` on env's current state."""
+    dist, idx, n = tables
+    home = C.c_int(-1)
+    m = lib().orc_bot_best(env.L.buf, env.S, int(agent), int(bool(defensive)), dist.ctypes, idx.ctypes, n, C.byref(home))
+    return m, home.value
+
+
+def set_bot_tables(tables):
+    dist, idx, n = tables
+    lib().orc_set_bot_tables(dist.ctypes, idx.ctypes, n)
+
+
 def maze_distances(rows):
     L = Layout(rows)
     cells = np.zeros((MAXD * MAXD, 2), np.int8)

@@ -9,6 +9,7 @@ from . import build as _build
 PMX_MAX_DIM = 32
 OBS_F32, OBS_BF16, OBS_U8 = 0, 1, 2
 ACTION_RANDOM_LEGAL = -2
+ACTION_BASELINE_OFFENSE, ACTION_BASELINE_DEFENSE = -3, -4
 LN32_PARTIAL_ROWS = 2048
 
 

@@ -29,6 +29,8 @@ struct pmx_env {
     std::vector<pmx_layout_host> layouts;
     std::vector<int32_t> layout_index;   // per env (empty: one layout)
     int32_t *layout_idx_dev;
+    uint8_t *dist_dev;           // maze-distance matrices of every layout, back to back (bots); NULL if too many layouts
+    int16_t *cell_index_dev;     // [n_layouts][1024]
     PmxLayoutDev *lay_dev;
     int8_t *dump_dev;
     uint32_t *state_dev;
@@ -98,6 +100,8 @@ void fill_tick_params(pmx_env *env, PmxTickParams &p, const int8_t *actions, con
     p.snap = env->snap_dev;
     p.lay = env->lay_dev;
     p.layout_idx = env->layout_idx_dev;
+    p.dist = env->dist_dev;
+    p.cell_index = env->cell_index_dev;
     p.dump = env->dump_dev;
     p.actions = actions;
     p.N = env->cfg.n_envs;
@@ -244,7 +248,14 @@ int pmx_create(const pmx_config *cfg, pmx_env **out)
         if (rc != PMX_OK) { delete env; return rc; }
     }
     const std::vector<int8_t> dump = dump_order(std::max(W, H));
-    for (auto &l : env->layouts) l.dev.n_dump = (int)(dump.size() / 2);
+    size_t dist_bytes = 0;
+    for (auto &l : env->layouts) {
+        l.dev.n_dump = (int)(dump.size() / 2);
+        l.dev.n_cells = (int)(l.cells.size() / 2);
+        l.dev.dist_off = (uint32_t)dist_bytes;
+        dist_bytes += (size_t)l.dev.n_cells * l.dev.n_cells;
+    }
+    const bool with_bots = dist_bytes <= ((size_t)1 << 31);      // the in-kernel reflex bots need every layout's distance matrix
     env->cfg = *cfg;
     env->cfg.wall_rows = env->cfg.food_rows = env->cfg.cap_rows = nullptr;
     env->cfg.starts = nullptr;
@@ -264,7 +275,7 @@ int pmx_create(const pmx_config *cfg, pmx_env **out)
         if ((mask >> i) & 1) env->emit[env->n_emit++] = i;
     env->elem_bytes = cfg->obs_dtype == PMX_OBS_F32 ? 4 : (cfg->obs_dtype == PMX_OBS_BF16 ? 2 : 1);
     env->lay_dev = nullptr; env->dump_dev = nullptr; env->state_dev = nullptr; env->snap_dev = nullptr;
-    env->layout_idx_dev = nullptr;
+    env->layout_idx_dev = nullptr; env->dist_dev = nullptr; env->cell_index_dev = nullptr;
     env->profiling = false; env->ev_rule_used = env->ev_expand_used = 0;
 
     hipError_t e = hipSetDevice(cfg->device);
@@ -281,6 +292,26 @@ int pmx_create(const pmx_config *cfg, pmx_env **out)
     if (e == hipSuccess) e = hipMemcpy(env->dump_dev, dump.data(), dump.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess && n_layouts > 1)
         e = hipMemcpy(env->layout_idx_dev, env->layout_index.data(), N * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && with_bots) {
+        // maze distances of every layout stay resident for the baselineTeam action codes (distanceCalculator.py:111-150)
+        std::vector<int16_t> idx_all;
+        std::vector<int8_t> cells_all;
+        for (auto &l : env->layouts) idx_all.insert(idx_all.end(), l.cell_index.begin(), l.cell_index.end());
+        e = hipMalloc((void **)&env->dist_dev, std::max<size_t>(dist_bytes, 1));
+        if (e == hipSuccess) e = hipMalloc((void **)&env->cell_index_dev, idx_all.size() * sizeof(int16_t));
+        if (e == hipSuccess) e = hipMemcpy(env->cell_index_dev, idx_all.data(), idx_all.size() * sizeof(int16_t), hipMemcpyHostToDevice);
+        int8_t *cells_dev = nullptr;
+        if (e == hipSuccess) e = hipMalloc((void **)&cells_dev, 2 * 1024);
+        for (size_t li = 0; e == hipSuccess && li < env->layouts.size(); ++li) {
+            const pmx_layout_host &lh = env->layouts[li];
+            e = hipMemcpy(cells_dev, lh.cells.data(), lh.cells.size(), hipMemcpyHostToDevice);
+            if (e == hipSuccess)
+                e = pmx_launch_maze(env->lay_dev + li, env->cell_index_dev + li * 1024, lh.dev.n_cells, cells_dev,
+                                    env->dist_dev + lh.dev.dist_off, nullptr);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+        }
+        if (cells_dev) (void)hipFree(cells_dev);
+    }
     if (e != hipSuccess) {
         pmx_destroy(env);
         return fail(e == hipErrorOutOfMemory ? PMX_ERR_NOMEM : PMX_ERR_HIP, "pmx_create: %s", hipGetErrorString(e));
@@ -300,6 +331,8 @@ int pmx_destroy(pmx_env *env)
     if (env->state_dev) (void)hipFree(env->state_dev);
     if (env->snap_dev) (void)hipFree(env->snap_dev);
     if (env->layout_idx_dev) (void)hipFree(env->layout_idx_dev);
+    if (env->dist_dev) (void)hipFree(env->dist_dev);
+    if (env->cell_index_dev) (void)hipFree(env->cell_index_dev);
     for (hipEvent_t e : env->ev_rule) (void)hipEventDestroy(e);
     for (hipEvent_t e : env->ev_expand) (void)hipEventDestroy(e);
     delete env;

@@ -44,6 +44,8 @@ struct PmxLayoutDev {
     int32_t total_food;
     int32_t n_dump;              // entries of the dump-order table
     uint32_t wall_stream[32];    // plane 0 of the observation as a packed bit stream: bit (y*W + x) = wall
+    int32_t n_cells;             // open cells (rows of this layout's maze-distance matrix)
+    uint32_t dist_off;           // byte offset of that matrix in the handle's distance buffer
 };
 
 struct PmxTickParams {
@@ -59,6 +61,8 @@ struct PmxTickParams {
     uint8_t *legal;
     int32_t *score_change;
     int32_t *score;
+    const uint8_t *dist;         // maze-distance matrices of all layouts (in-kernel baselineTeam bots), or NULL
+    const int16_t *cell_index;   // [n_layouts][32*32] cell -> row of the distance matrix
     uint32_t *agent_out;         // [N][4] x | y<<8 | carry<<16 right after the agent's own sub-step
     uint32_t seed;
     const uint8_t *reset_mask;   // reset kernel only: NULL = every env

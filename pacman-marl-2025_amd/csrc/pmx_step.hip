@@ -42,6 +42,10 @@ struct Ctx {
     int legal_reward, defence_reward;
     uint32_t rng_key;     // seed ^ env * 0x9E3779B1 (the per-env part of the random-legal key)
     uint32_t start_xy[4]; // start cells, packed like Env::xy
+    uint32_t *fd2;        // LDS: scratch food column for the reflex bots' what-if successors
+    const uint8_t *dist;  // this env's layout's maze-distance matrix (or NULL)
+    const int16_t *cidx;  // its cell -> matrix row map
+    int n_cells;
 };
 
 __device__ __forceinline__ uint32_t pack_a(const Env &e, int i)
@@ -163,14 +167,13 @@ __device__ __forceinline__ int random_legal(int legal, uint32_t key, uint32_t ti
 }
 
 template <int I>
-__device__ __forceinline__ int substep(Env &e, const Ctx &c, int action, bool &req_legal, int &d_red, int &d_blue)
+__device__ __forceinline__ int substep_core(Env &e, const Ctx &c, int action, bool &req_legal, int &d_red, int &d_blue)
 {
     constexpr bool RED = (I % 2) == 0;
     constexpr int O1 = RED ? 1 : 0, O2 = O1 + 2;
     // ---- applyAction capture.py:468-517
     int px = e.xy[I] & 0xFF, py = e.xy[I] >> 8;
     const int legal = legal_mask(c.wl, c.wls, px, py);
-    if (action == -2) action = random_legal(legal, c.rng_key, e.ticks, I);
     req_legal = (action >= 0) && (action <= 4) && ((legal >> (action & 7)) & 1);
     if (!req_legal) action = 4;                                           // :473-474
     px += (action == 1) - (action == 3); py += (action == 0) - (action == 2);
@@ -213,6 +216,79 @@ __device__ __forceinline__ int substep(Env &e, const Ctx &c, int action, bool &r
     e.scared[I] = e.scared[I] > 1 ? e.scared[I] - 1 : 0;                  // capture.py:562-567, mover only
     e.score += sc;                                                        // capture.py:121
     return sc;
+}
+
+// agents/baselineTeam.py:65-187 evaluated in the kernel (action codes -3 offensive / -4 defensive, include/pmx.h): the
+// successor of every legal action is generated for real (on a register copy of the agents and a scratch LDS copy of the
+// food column), scored with the reference's features x weights, and one of the best actions is drawn with the
+// counter-based generator; with no food left to eat the agent walks home (:81-90).
+template <int I>
+__device__ __noinline__ int bot_action(const Env &e, const Ctx &c, bool defensive)
+{
+    constexpr bool RED = (I % 2) == 0;
+    constexpr int O1 = RED ? 1 : 0, O2 = O1 + 2;
+    const int legal = legal_mask(c.wl, c.wls, (int)(e.xy[I] & 0xFF), (int)(e.xy[I] >> 8));
+    const uint32_t enemy_mask = RED ? c.L->hi_mask : c.L->lo_mask;      // getFood: the other side's pellets
+    int food_left = 0;
+    for (int y = 0; y < c.H; ++y) food_left += __popc(c.fd[y * PMX_RULE_BLOCK] & enemy_mask);
+    const int start_idx = c.cidx[(c.start_xy[I] >> 8) * 32 + (c.start_xy[I] & 0xFF)];
+    int best = -(1 << 30), best_mask = 0, home_best = 9999, home_act = -1;
+    const int order[5] = { 0, 2, 1, 3, 4 };
+    const int rev[5] = { 2, 3, 0, 1, 4 };
+    for (int k = 0; k < 5; ++k) {
+        const int a = order[k];
+        if (!((legal >> a) & 1)) continue;
+        Env t = e;
+        for (int y = 0; y < c.H; ++y) c.fd2[y * PMX_RULE_BLOCK] = c.fd[y * PMX_RULE_BLOCK];
+        Ctx c2 = c;
+        c2.fd = c.fd2;
+        bool rl; int dr = 0, db = 0;
+        substep_core<I>(t, c2, a, rl, dr, db);
+        const int my = c.cidx[(t.xy[I] >> 8) * 32 + (t.xy[I] & 0xFF)];
+        const uint8_t *drow = c.dist + (size_t)my * c.n_cells;
+        int val;
+        if (!defensive) {
+            int cnt = 0, mind = 1 << 30;
+            for (int y = 0; y < c.H; ++y) {
+                uint32_t m = c.fd2[y * PMX_RULE_BLOCK] & enemy_mask;
+                cnt += __popc(m);
+                while (m) {
+                    const int x = __ffs(m) - 1;
+                    m &= m - 1;
+                    const int d = drow[c.cidx[y * 32 + x]];
+                    mind = d < mind ? d : mind;
+                }
+            }
+            val = -100 * cnt - (cnt > 0 ? mind : 0);
+        } else {
+            int num_inv = 0, mind = 1 << 30;
+            if (t.pac[O1]) { ++num_inv; const int d = drow[c.cidx[(t.xy[O1] >> 8) * 32 + (t.xy[O1] & 0xFF)]]; mind = d < mind ? d : mind; }
+            if (t.pac[O2]) { ++num_inv; const int d = drow[c.cidx[(t.xy[O2] >> 8) * 32 + (t.xy[O2] & 0xFF)]]; mind = d < mind ? d : mind; }
+            val = -1000 * num_inv + 100 * (t.pac[I] ? 0 : 1) - (num_inv > 0 ? 10 * mind : 0) - (a == 4 ? 100 : 0) - (a == rev[e.dir[I]] ? 2 : 0);
+        }
+        if (val > best) { best = val; best_mask = 1 << a; }
+        else if (val == best) best_mask |= 1 << a;
+        const int hd = c.dist[(size_t)start_idx * c.n_cells + my];
+        if (hd < home_best) { home_best = hd; home_act = a; }
+    }
+    if (food_left <= 0) return home_act;
+    uint32_t x = c.rng_key ^ (e.ticks * 0x85EBCA77u) ^ ((uint32_t)I * 0xC2B2AE3Du) ^ 0x5bd1e995u;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    int kk = (int)(((uint64_t)x * (uint32_t)__popc(best_mask)) >> 32);
+    int pick = 4;
+    for (int j = 0; j < 5; ++j) {
+        const int a = order[j];
+        if ((best_mask >> a) & 1) { if (kk == 0) pick = a; --kk; }
+    }
+    return pick;
+}
+
+template <int I>
+__device__ __forceinline__ int substep(Env &e, const Ctx &c, int action, bool &req_legal, int &d_red, int &d_blue)
+{
+    if (action == -2) action = random_legal(legal_mask(c.wl, c.wls, (int)(e.xy[I] & 0xFF), (int)(e.xy[I] >> 8)), c.rng_key, e.ticks, I);
+    else if ((action == -3 || action == -4) && c.dist) action = bot_action<I>(e, c, action == -4);
+    return substep_core<I>(e, c, action, req_legal, d_red, d_blue);
 }
 
 // One iteration of the loop gymPacMan.py:149-169 for agent I: shaped reward (from the successor, which is what the
@@ -347,6 +423,10 @@ __device__ __forceinline__ Ctx make_ctx(const PmxTickParams &p, uint32_t *lds)
     c.wl = multi ? lds + 32 + PMX_MAX_H_LDS * PMX_RULE_BLOCK + threadIdx.x : lds;
     c.wls = multi ? PMX_RULE_BLOCK : 1;
     c.fd = lds + 32 + threadIdx.x;
+    c.fd2 = multi ? lds + 32 + 2 * PMX_MAX_H_LDS * PMX_RULE_BLOCK + threadIdx.x : lds + 32 + c.H * PMX_RULE_BLOCK + threadIdx.x;
+    c.dist = p.dist ? p.dist + c.L->dist_off : nullptr;
+    c.cidx = p.cell_index ? p.cell_index + (size_t)(c.L - p.lay) * 1024 : nullptr;
+    c.n_cells = c.L->n_cells;
 #pragma unroll
     for (int i = 0; i < 4; ++i) c.start_xy[i] = (uint32_t)c.L->startx[i] | ((uint32_t)c.L->starty[i] << 8);
     c.rng_key = p.seed ^ ((uint32_t)(blockIdx.x * PMX_RULE_BLOCK + threadIdx.x) * 0x9E3779B1u);
@@ -629,7 +709,7 @@ __global__ __launch_bounds__(PMX_BLOCK) void pmx_expand_kernel(PmxExpandParams p
 extern "C" hipError_t pmx_launch_rule(const PmxTickParams *p, int H, hipStream_t st)
 {
     const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
-    const size_t lds = (p->layout_idx ? 32 + (size_t)(PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)H * PMX_RULE_BLOCK) * sizeof(uint32_t);
+    const size_t lds = (p->layout_idx ? 32 + (size_t)(2 * PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)2 * H * PMX_RULE_BLOCK) * sizeof(uint32_t);
     hipLaunchKernelGGL(pmx_rule_kernel, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p);
     return hipGetLastError();
 }
@@ -637,7 +717,7 @@ extern "C" hipError_t pmx_launch_rule(const PmxTickParams *p, int H, hipStream_t
 extern "C" hipError_t pmx_launch_rule_agent(const PmxTickParams *p, int H, int agent, hipStream_t st)
 {
     const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
-    const size_t lds = (p->layout_idx ? 32 + (size_t)(PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)H * PMX_RULE_BLOCK) * sizeof(uint32_t);
+    const size_t lds = (p->layout_idx ? 32 + (size_t)(2 * PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)2 * H * PMX_RULE_BLOCK) * sizeof(uint32_t);
     hipLaunchKernelGGL(pmx_rule_agent_kernel, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p, agent);
     return hipGetLastError();
 }
@@ -645,7 +725,7 @@ extern "C" hipError_t pmx_launch_rule_agent(const PmxTickParams *p, int H, int a
 extern "C" hipError_t pmx_launch_successor(const PmxTickParams *p, int H, int agent, hipStream_t st)
 {
     const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
-    const size_t lds = (p->layout_idx ? 32 + (size_t)(PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)H * PMX_RULE_BLOCK) * sizeof(uint32_t);
+    const size_t lds = (p->layout_idx ? 32 + (size_t)(2 * PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)2 * H * PMX_RULE_BLOCK) * sizeof(uint32_t);
     hipLaunchKernelGGL(pmx_successor_kernel, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p, agent);
     return hipGetLastError();
 }
@@ -653,7 +733,7 @@ extern "C" hipError_t pmx_launch_successor(const PmxTickParams *p, int H, int ag
 extern "C" hipError_t pmx_launch_reset(const PmxTickParams *p, int H, hipStream_t st)
 {
     const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
-    const size_t lds = (p->layout_idx ? 32 + (size_t)(PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)H * PMX_RULE_BLOCK) * sizeof(uint32_t);
+    const size_t lds = (p->layout_idx ? 32 + (size_t)(2 * PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)2 * H * PMX_RULE_BLOCK) * sizeof(uint32_t);
     hipLaunchKernelGGL(pmx_reset_kernel, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p);
     return hipGetLastError();
 }

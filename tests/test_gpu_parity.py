@@ -448,3 +448,36 @@ def test_other_board_sizes_vs_oracle(rows_cols, dtype, N):
     oc, od = O.maze_distances(rows)
     assert (cells.cpu().numpy() == oc).all() and (dist.cpu().numpy() == od).all()
     env.close()
+
+
+@pytest.mark.parametrize("layname", ["smallCapture", "tinyCapture"])
+def test_in_kernel_baseline_bots_vs_oracle(layname):
+    """Action codes -3 / -4 (the reference's reflex agents evaluated in the kernel on the mid-tick state) against the oracle's
+    restatement, which tests/test_oracle_golden.py pins to the reference's own bot traces (fixture G9)."""
+    pmx = _pmx()
+    lay = pmx.get_layout(layname)
+    N, T = 320, 340
+    env = pmx.PmxVecEnv(lay, N, length=150, auto_reset=True, seed=21)
+    orc = O.BatchEnv(lay.text, N, length=150, auto_reset=True, seed=21)
+    O.set_bot_tables(O.bot_tables(lay.text))
+    env.reset()
+    rng = np.random.RandomState(4)
+    oobs = np.zeros((N, 4, 8, lay.height, lay.width), np.float32)
+    score_seen = set()
+    for t in range(T):
+        a = rng.randint(0, 5, size=(N, 4)).astype(np.int8)
+        a[:, 0] = -3                                   # red: baselineTeam (offensive agent 0, defensive agent 2)
+        a[:, 2] = -4
+        a[: N // 2, 1] = -3                            # half of the envs: bots on both sides, blue 1 offensive, blue 3 defensive
+        a[: N // 2, 3] = -4
+        a[N // 2:, 1][rng.rand(N - N // 2) < 0.5] = -2
+        orc.tick(a, oobs)
+        obs, rew, done, info = env.step(torch.tensor(a).cuda())
+        assert rew.cpu().numpy().tobytes() == orc.reward.tobytes(), t
+        assert (done.cpu().numpy() == orc.done).all() and (info["legal_actions"].cpu().numpy() == orc.legal).all(), t
+        assert (info["agent"].cpu().numpy().astype(np.uint32) == orc.agent).all(), t
+        assert (info["score"].cpu().numpy() == orc.score).all(), t
+        assert (obs.cpu().numpy() == oobs).all(), t
+        score_seen.update(orc.score.tolist())
+    assert len(score_seen) > 3                         # the bots do eat and return food
+    env.close()

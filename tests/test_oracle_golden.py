@@ -108,3 +108,30 @@ def test_dump_order_prefix():
             (2, 2), (-3, -3)]
     assert [tuple(x) for x in o[:len(want)]] == want
     assert len(o) == 49 and len({tuple(x) for x in o}) == 49
+
+
+@pytest.mark.parametrize("fixture", ["bots_tiny_baselineTeam.json", "bots_small_baselineTeam.json"])
+def test_baseline_bot_evaluation_matches_reference_traces(fixture):
+    """The in-kernel baselineTeam bots (action codes -3 / -4) re-state the reference's reflex evaluation; its tie-break
+    uses a different generator, so the check is: every action the reference's bots took (fixture G9) is in the best set
+    computed here on the same mid-tick state (and equals the "walk home" action when that rule fires)."""
+    g = G.load_json(fixture)
+    env = O.Env(g["layout"], g["length"])
+    scratch = O.Env(g["layout"], g["length"])
+    tables = O.bot_tables(g["layout"])
+    n_multi = 0
+    for t, (a1, a3) in enumerate(g["blue_actions"]):
+        ra = g["red_actions"][t]                                   # the recorder was re-hooked after every reset: k copies each
+        r0, r2 = ra[0], ra[len(ra) // 2]
+        m0, h0 = O.bot_best(env, 0, False, tables)                 # agent 0 = OffensiveReflexAgent (createTeam, :34-50)
+        assert (h0 == r0) if h0 >= 0 else ((m0 >> r0) & 1), (t, "offense", m0, h0, r0)
+        scratch.set_state(env.get_state())
+        scratch.substep(0, r0); scratch.substep(1, a1)
+        m2, h2 = O.bot_best(scratch, 2, True, tables)              # agent 2 = DefensiveReflexAgent
+        assert (h2 == r2) if h2 >= 0 else ((m2 >> r2) & 1), (t, "defense", m2, h2, r2)
+        n_multi += bin(m0).count("1") > 1
+        r = env.tick([r0, a1, r2, a3])
+        assert r["done"] == int(g["dones"][t])
+        if r["done"]:
+            env.reset()
+    assert n_multi > 0                                             # ties do occur, so the set check is not vacuous
