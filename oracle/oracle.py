@@ -244,7 +244,14 @@ def bot_best(env, agent, defensive, tables):
     return m, home.value
 
 
+_bot_keep = None
+
+
 def set_bot_tables(tables):
+    """Install the distance tables the oracle uses for action codes -3 / -4 (the C side keeps raw pointers, so the arrays
+    are held here for as long as they are installed)."""
+    global _bot_keep
+    _bot_keep = tables
     dist, idx, n = tables
     lib().orc_set_bot_tables(dist.ctypes, idx.ctypes, n)
 
