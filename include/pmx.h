@@ -53,8 +53,8 @@ enum { PMX_OBS_F32 = 0, PMX_OBS_BF16 = 1, PMX_OBS_U8 = 2 };
  * the agent on the mid-tick state with the reference's reflex features and weights (offensive: -100 * food left - maze
  * distance to the nearest pellet; defensive: invaders, on-defence, invader distance, stop, reverse) and plays one of the
  * best actions (tie-break by the counter-based generator instead of random.choice); with no food left the agent walks home.
- * Needs the layouts' maze-distance matrices resident on the device (kept when they total <= 2 GiB; otherwise the codes
- * act as Stop). */
+ * Only handles created with pmx_config.enable_bots understand these codes (the layouts' maze-distance matrices then stay
+ * resident on the device, at most 2 GiB); elsewhere they act as Stop. */
 #define PMX_ACTION_BASELINE_OFFENSE (-3)
 #define PMX_ACTION_BASELINE_DEFENSE (-4)
 
@@ -84,6 +84,8 @@ typedef struct {
                                     (gymPacMan's random_layout=True draws a new maze per reset, gymPacMan.py:98-100; here
                                     each env keeps the maze it is given) */
     const int32_t *layout_index; /* [n_envs] host array: layout of each env (required when n_layouts > 1) */
+    int32_t enable_bots;         /* 1: keep every layout's maze-distance matrix on the device and use the tick kernel variant
+                                    that understands PMX_ACTION_BASELINE_* (it is a few microseconds per tick slower) */
 } pmx_config;
 
 /* Outputs of one tick = what gymPacMan.step returns (gymPacMan.py:191-193), batched.  Any pointer may be

@@ -24,7 +24,7 @@ class Config(C.Structure):
                 ("n_envs", C.c_int32), ("length", C.c_int32), ("legal_reward", C.c_int32),
                 ("defence_reward", C.c_int32), ("auto_reset", C.c_int32), ("obs_dtype", C.c_int32),
                 ("obs_agents", C.c_int32), ("device", C.c_int32), ("seed", C.c_uint32), ("n_layouts", C.c_int32),
-                ("layout_index", C.POINTER(C.c_int32))]
+                ("layout_index", C.POINTER(C.c_int32)), ("enable_bots", C.c_int32)]
 
 
 class StepOut(C.Structure):

@@ -255,7 +255,9 @@ int pmx_create(const pmx_config *cfg, pmx_env **out)
         l.dev.dist_off = (uint32_t)dist_bytes;
         dist_bytes += (size_t)l.dev.n_cells * l.dev.n_cells;
     }
-    const bool with_bots = dist_bytes <= ((size_t)1 << 31);      // the in-kernel reflex bots need every layout's distance matrix
+    // the in-kernel reflex bots need every layout's distance matrix resident; only handles that ask for them pay
+    if (cfg->enable_bots && dist_bytes > ((size_t)1 << 31)) { delete env; return fail(PMX_ERR_UNSUPPORTED, "enable_bots: the layouts' distance matrices exceed 2 GiB"); }
+    const bool with_bots = cfg->enable_bots != 0;
     env->cfg = *cfg;
     env->cfg.wall_rows = env->cfg.food_rows = env->cfg.cap_rows = nullptr;
     env->cfg.starts = nullptr;

@@ -283,17 +283,21 @@ __device__ __noinline__ int bot_action(const Env &e, const Ctx &c, bool defensiv
     return pick;
 }
 
-template <int I>
+// BOTS: the handle was created with pmx_config.enable_bots; only that kernel variant carries the reflex-bot code (it costs
+// registers and a stack frame for the agent state: +3 us per tick on 16 k envs even when no bot code is used)
+template <int I, bool BOTS>
 __device__ __forceinline__ int substep(Env &e, const Ctx &c, int action, bool &req_legal, int &d_red, int &d_blue)
 {
     if (action == -2) action = random_legal(legal_mask(c.wl, c.wls, (int)(e.xy[I] & 0xFF), (int)(e.xy[I] >> 8)), c.rng_key, e.ticks, I);
-    else if ((action == -3 || action == -4) && c.dist) action = bot_action<I>(e, c, action == -4);
+    if constexpr (BOTS) {
+        if ((action == -3 || action == -4) && c.dist) action = bot_action<I>(e, c, action == -4);
+    }
     return substep_core<I>(e, c, action, req_legal, d_red, d_blue);
 }
 
 // One iteration of the loop gymPacMan.py:149-169 for agent I: shaped reward (from the successor, which is what the
 // reference's shadow successor equals) + the transition itself.
-template <int I>
+template <int I, bool BOTS>
 __device__ __forceinline__ void tick_substep(Env &e, Acc &a, const Ctx &c, int action)
 {
     constexpr bool RED = (I % 2) == 0;
@@ -301,7 +305,7 @@ __device__ __forceinline__ void tick_substep(Env &e, Acc &a, const Ctx &c, int a
     const int pac1 = e.pac[O1], pac2 = e.pac[O2];
     bool req_legal;
     int d_red = 0, d_blue = 0;
-    const int sc = substep<I>(e, c, action, req_legal, d_red, d_blue);
+    const int sc = substep<I, BOTS>(e, c, action, req_legal, d_red, d_blue);
     double r = RED ? a.red_r : a.blue_r;
     if (RED) {                                                            // gymPacMan.py:233-242
         if (d_red > 0) r += 1.0;
@@ -442,7 +446,8 @@ __device__ __forceinline__ Ctx make_ctx(const PmxTickParams &p, uint32_t *lds)
 }  // namespace
 
 // dynamic LDS: 32 wall rows + H food rows x PMX_RULE_BLOCK lanes
-extern "C" __global__ __launch_bounds__(PMX_RULE_BLOCK) void pmx_rule_kernel(PmxTickParams p)
+template <bool BOTS>
+__global__ __launch_bounds__(PMX_RULE_BLOCK) void pmx_rule_kernel(PmxTickParams p)
 {
     extern __shared__ uint32_t lds[];
     Ctx c = make_ctx(p, lds);
@@ -453,19 +458,19 @@ extern "C" __global__ __launch_bounds__(PMX_RULE_BLOCK) void pmx_rule_kernel(Pmx
     Acc a = { 0.0, 0.0, 0, 0, 0 };
     const uint32_t av = reinterpret_cast<const uint32_t *>(p.actions)[env];   // 4 int8 actions
     const size_t snap_sz = (size_t)PMX_SNAP_WORDS(c.H) * p.N;
-    tick_substep<0>(e, a, c, (int)(int8_t)(av & 0xFF));
+    tick_substep<0, BOTS>(e, a, c, (int)(int8_t)(av & 0xFF));
     store_snapshot(e, c, p.snap, p.N, env);
-    tick_substep<1>(e, a, c, (int)(int8_t)((av >> 8) & 0xFF));
+    tick_substep<1, BOTS>(e, a, c, (int)(int8_t)((av >> 8) & 0xFF));
     store_snapshot(e, c, p.snap + snap_sz, p.N, env);
-    tick_substep<2>(e, a, c, (int)(int8_t)((av >> 16) & 0xFF));
+    tick_substep<2, BOTS>(e, a, c, (int)(int8_t)((av >> 16) & 0xFF));
     store_snapshot(e, c, p.snap + 2 * snap_sz, p.N, env);
-    tick_substep<3>(e, a, c, (int)(int8_t)((av >> 24) & 0xFF));
+    tick_substep<3, BOTS>(e, a, c, (int)(int8_t)((av >> 24) & 0xFF));
     tick_finish(e, a, c, p, env, true);
     store_env(e, c, p.state, p.N, env);
 }
 
 // pmx_step_agent: one sub-step; the accumulators of the open tick travel through the state words.
-template <int I>
+template <int I, bool BOTS>
 __device__ __forceinline__ void rule_agent_body(const PmxTickParams &p, uint32_t *lds)
 {
     Ctx c = make_ctx(p, lds);
@@ -483,7 +488,7 @@ __device__ __forceinline__ void rule_agent_body(const PmxTickParams &p, uint32_t
 #pragma unroll
     for (int i = 0; i < 4; ++i)   // sub-steps not yet taken report the current state
         e.self_after[i] = e.xy[i] | ((uint32_t)e.carry[i] << 16);
-    tick_substep<I>(e, a, c, (int)p.actions[env]);
+    tick_substep<I, BOTS>(e, a, c, (int)p.actions[env]);
     if (p.agent_out) p.agent_out[4 * (size_t)env + I] = e.self_after[I];
     if (I == 3) {
         tick_finish(e, a, c, p, env, false);
@@ -506,7 +511,7 @@ __device__ __forceinline__ void successor_body(const PmxTickParams &p, uint32_t 
     load_env(e, c, p.state, p.N, env);
     bool req_legal;
     int d_red = 0, d_blue = 0;
-    const int sc = substep<I>(e, c, (int)p.actions[env], req_legal, d_red, d_blue);
+    const int sc = substep<I, false>(e, c, (int)p.actions[env], req_legal, d_red, d_blue);
     if (p.score_change) p.score_change[env] = sc;
     store_env(e, c, p.state, p.N, env);
 }
@@ -522,14 +527,15 @@ extern "C" __global__ __launch_bounds__(PMX_RULE_BLOCK) void pmx_successor_kerne
     }
 }
 
-extern "C" __global__ __launch_bounds__(PMX_RULE_BLOCK) void pmx_rule_agent_kernel(PmxTickParams p, int agent)
+template <bool BOTS>
+__global__ __launch_bounds__(PMX_RULE_BLOCK) void pmx_rule_agent_kernel(PmxTickParams p, int agent)
 {
     extern __shared__ uint32_t lds[];
     switch (agent) {   // wave-uniform
-    case 0: rule_agent_body<0>(p, lds); break;
-    case 1: rule_agent_body<1>(p, lds); break;
-    case 2: rule_agent_body<2>(p, lds); break;
-    default: rule_agent_body<3>(p, lds); break;
+    case 0: rule_agent_body<0, BOTS>(p, lds); break;
+    case 1: rule_agent_body<1, BOTS>(p, lds); break;
+    case 2: rule_agent_body<2, BOTS>(p, lds); break;
+    default: rule_agent_body<3, BOTS>(p, lds); break;
     }
 }
 
@@ -710,7 +716,8 @@ extern "C" hipError_t pmx_launch_rule(const PmxTickParams *p, int H, hipStream_t
 {
     const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
     const size_t lds = (p->layout_idx ? 32 + (size_t)(2 * PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)2 * H * PMX_RULE_BLOCK) * sizeof(uint32_t);
-    hipLaunchKernelGGL(pmx_rule_kernel, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p);
+    if (p->dist) hipLaunchKernelGGL(pmx_rule_kernel<true>, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p);
+    else hipLaunchKernelGGL(pmx_rule_kernel<false>, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p);
     return hipGetLastError();
 }
 
@@ -718,7 +725,8 @@ extern "C" hipError_t pmx_launch_rule_agent(const PmxTickParams *p, int H, int a
 {
     const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
     const size_t lds = (p->layout_idx ? 32 + (size_t)(2 * PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)2 * H * PMX_RULE_BLOCK) * sizeof(uint32_t);
-    hipLaunchKernelGGL(pmx_rule_agent_kernel, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p, agent);
+    if (p->dist) hipLaunchKernelGGL(pmx_rule_agent_kernel<true>, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p, agent);
+    else hipLaunchKernelGGL(pmx_rule_agent_kernel<false>, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p, agent);
     return hipGetLastError();
 }
 

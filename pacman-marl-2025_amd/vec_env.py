@@ -24,7 +24,7 @@ def legal_list(mask):
 
 class PmxVecEnv:
     def __init__(self, layout, n_envs, length=299, reward_forLegalAction=True, defenceReward=True, auto_reset=True,
-                 obs_dtype="float32", obs_agents=(0, 1, 2, 3), device="cuda:0", seed=0, layout_index=None):
+                 obs_dtype="float32", obs_agents=(0, 1, 2, 3), device="cuda:0", seed=0, layout_index=None, bots=False):
         if not torch.cuda.is_available():
             raise _lib.PmxError("PmxVecEnv needs a GPU: the product has no CPU path")
         self.lib = _lib.load()
@@ -73,6 +73,7 @@ class PmxVecEnv:
         cfg.obs_agents = sum(1 << a for a in self.obs_agents)
         cfg.device = self.device.index or 0
         cfg.seed = int(seed) & 0xFFFFFFFF
+        cfg.enable_bots = int(bool(bots))          # understand ACTION_BASELINE_OFFENSE / _DEFENSE (in-kernel baselineTeam)
         self.handle = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.pmx_create(C.byref(cfg), C.byref(self.handle)), "pmx_create")

@@ -457,7 +457,7 @@ def test_in_kernel_baseline_bots_vs_oracle(layname):
     pmx = _pmx()
     lay = pmx.get_layout(layname)
     N, T = 320, 340
-    env = pmx.PmxVecEnv(lay, N, length=150, auto_reset=True, seed=21)
+    env = pmx.PmxVecEnv(lay, N, length=150, auto_reset=True, seed=21, bots=True)
     orc = O.BatchEnv(lay.text, N, length=150, auto_reset=True, seed=21)
     O.set_bot_tables(O.bot_tables(lay.text))
     env.reset()
