@@ -479,5 +479,5 @@ def test_in_kernel_baseline_bots_vs_oracle(layname):
         assert (info["score"].cpu().numpy() == orc.score).all(), t
         assert (obs.cpu().numpy() == oobs).all(), t
         score_seen.update(orc.score.tolist())
-    assert len(score_seen) > 3                         # the bots do eat and return food
+    assert len(score_seen) >= 2                        # the bots do eat and return food (the reference scores 11 at once on tiny)
     env.close()
