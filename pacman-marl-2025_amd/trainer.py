@@ -6,8 +6,9 @@ Per update (pacman_mappo_resnet.py:385-600), with N envs in lock-step instead of
            (:241-264, :513-522), store everything in DEVICE-resident buffers (:449-455 kept them on the CPU)
   GAE      pmx_gae over the [T][2N] series (:548-553)
   update   UPDATE_EPOCHS x minibatches of the flattened [T*N*2] samples through PPOLearner (:556-595)
-Opponents: the in-kernel randomTeam bot (PMX_ACTION_RANDOM_LEGAL), the current network, or a frozen EMA snapshot from
-the opponent pool (:396-438; the scripted bot zoo of the reference's curriculum is out of scope).
+Opponents: the in-kernel randomTeam and baselineTeam bots (PMX_ACTION_RANDOM_LEGAL / PMX_ACTION_BASELINE_*), the current
+network, or a frozen EMA snapshot from the opponent pool (:396-438; the A*/MCTS/approx-Q teams of the reference's
+curriculum are out of scope).
 """
 import copy
 import ctypes as C
@@ -58,7 +59,8 @@ class VecMAPPOTrainer:
         self.device = torch.device(device)
         self.rank, self.world_size = rank, world_size
         self.env = PmxVecEnv(layout, n_envs, length=length, reward_forLegalAction=True, defenceReward=True,
-                             auto_reset=True, obs_dtype=obs_dtype, device=self.device, seed=seed * 1000003 + rank)
+                             auto_reset=True, obs_dtype=obs_dtype, device=self.device, seed=seed * 1000003 + rank,
+                             bots=opponent in ("baseline", "curriculum"))
         self.N, self.T = n_envs, horizon
         self.minibatch, self.epochs = minibatch, epochs
         # "mappo": centralised critic on merge_obs_for_critic of the two learners (the reference).  "ippo": the same network
@@ -83,7 +85,7 @@ class VecMAPPOTrainer:
         self.opponent_model.eval()
         self.opponent_pool = deque(maxlen=OPPONENT_POOL_SIZE)
         self.opponent_pool.append(self.learner.ema_state_dict())
-        self.opponent_mode = opponent                              # "random" | "self" | "pool" | "curriculum"
+        self.opponent_mode = opponent                              # "random" | "baseline" | "self" | "pool" | "curriculum"
         self.gen = torch.Generator(device=self.device).manual_seed(seed * 7919 + rank)
         self.np_rng = np.random.RandomState(seed * 31 + rank)
         dt, dev, N, T = self.env.obs_torch_dtype, self.device, n_envs, horizon
@@ -127,11 +129,15 @@ class VecMAPPOTrainer:
         """The self-play part of the curriculum (pacman_mappo_resnet.py:396-438) with the opponents this build has."""
         mode = self.opponent_mode
         if mode == "curriculum":
+            # :396-438 with the opponents this build has on the GPU: randomTeam first, then randomTeam / baselineTeam
+            # (the reference weights its "hard" teams, baselineTeam among them, 5x), then 40 % self / 20 % pool / 40 % bots
             if self.update_idx <= 200:
                 mode = "random"
+            elif self.update_idx <= 800:
+                mode = "baseline" if self.np_rng.rand() < 5.0 / 6.0 else "random"
             else:
                 r = self.np_rng.rand()
-                mode = "self" if r < 0.40 else ("pool" if r < 0.60 else "random")
+                mode = "self" if r < 0.40 else ("pool" if r < 0.60 else ("baseline" if self.np_rng.rand() < 5.0 / 6.0 else "random"))
         play_as_red = False
         if mode == "self":
             play_as_red = bool(self.np_rng.rand() > 0.5)
@@ -167,6 +173,9 @@ class VecMAPPOTrainer:
             self.act_buf[t].copy_(a)
             self.logp_buf[t].copy_(lp)
             acts = torch.full((N, 4), _lib.ACTION_RANDOM_LEGAL, dtype=torch.int8, device=self.device)
+            if mode == "baseline":                                   # createTeam: first index offensive, second defensive
+                acts[:, opp_ids[0]] = _lib.ACTION_BASELINE_OFFENSE
+                acts[:, opp_ids[1]] = _lib.ACTION_BASELINE_DEFENSE
             acts[:, learner_ids] = mappo.canonicalize_action(a, red).to(torch.int8)
             if mode in ("self", "pool"):
                 oo = raw[:, opp_ids]

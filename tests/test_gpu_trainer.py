@@ -71,7 +71,7 @@ def test_ppo_loss_on_gpu_fp32_matches_reference():
     _close(float(learner.bucket.data.double().sum()), d["post_adam_sum"], rtol=1e-5)
 
 
-@pytest.mark.parametrize("opponent,dtype,algorithm", [("random", "bfloat16", "mappo"), ("self", "uint8", "mappo"), ("random", "bfloat16", "ippo")])
+@pytest.mark.parametrize("opponent,dtype,algorithm", [("random", "bfloat16", "mappo"), ("self", "uint8", "mappo"), ("random", "bfloat16", "ippo"), ("baseline", "bfloat16", "mappo")])
 def test_rollout_gae_update_end_to_end(opponent, dtype, algorithm):
     import pmx
     from pmx import trainer

@@ -18,7 +18,7 @@ ap.add_argument("--minibatch", type=int, default=8192, help="samples per optimiz
 ap.add_argument("--epochs", type=int, default=3)
 ap.add_argument("--updates", type=int, default=10)
 ap.add_argument("--total-updates", type=int, default=2000)
-ap.add_argument("--opponent", default="curriculum", choices=["random", "self", "pool", "curriculum"])
+ap.add_argument("--opponent", default="curriculum", choices=["random", "baseline", "self", "pool", "curriculum"])
 ap.add_argument("--obs", default="bfloat16")
 ap.add_argument("--algorithm", default="mappo", choices=["mappo", "ippo"])
 ap.add_argument("--eval-every", type=int, default=0)
