@@ -301,6 +301,43 @@ def evaluate_vs_bots(model, num_episodes=20, layout_file="bloxCapture", teams=("
     return float(np.mean(returns)), float(np.std(returns)), wins / num_episodes
 
 
+@torch.no_grad()
+def evaluate_vectorized(model, layout="bloxCapture", n_envs=1024, opponent="baseline", length=300, device="cuda:0", seed=0,
+                        autocast=True):
+    """evaluate_vs_bots (pacman_mappo_resnet.py:293-337) for n_envs episodes at once: the learner plays blue with argmax
+    actions against the in-kernel randomTeam / baselineTeam, one episode per env (an env stops counting at its first done).
+    Returns (mean episode return of the learner team as the reference sums it, std, win rate = share with final score < 0)."""
+    dev = torch.device(device)
+    env = PmxVecEnv(layout, n_envs, length=length, auto_reset=True, obs_dtype="bfloat16" if autocast else "float32", device=dev,
+                    seed=seed, bots=(opponent == "baseline"))
+    obs, _ = env.reset()
+    was_training = model.training
+    model.eval()
+    alive = torch.ones(n_envs, dtype=torch.bool, device=dev)
+    ret = torch.zeros(n_envs, dtype=torch.float64, device=dev)
+    final = torch.zeros(n_envs, dtype=torch.int32, device=dev)
+    opp = (_lib.ACTION_BASELINE_OFFENSE, _lib.ACTION_BASELINE_DEFENSE) if opponent == "baseline" else (_lib.ACTION_RANDOM_LEGAL,) * 2
+    ctx = torch.autocast(device_type=dev.type, dtype=torch.bfloat16) if autocast else _NullCtx()
+    for _ in range(length + 1):
+        lo = obs[:, [1, 3]].reshape((-1,) + tuple(obs.shape[2:]))
+        with ctx:
+            a = model.get_deterministic_action(lo.to(torch.bfloat16) if autocast else lo.float()).view(n_envs, 2)
+        acts = torch.empty((n_envs, 4), dtype=torch.int8, device=dev)
+        acts[:, 0], acts[:, 2] = opp[0], opp[1]
+        acts[:, [1, 3]] = a.to(torch.int8)
+        obs, rew, done, info = env.step(acts)
+        ret += torch.where(alive, rew[:, 1] + rew[:, 1], torch.zeros_like(ret))     # sum over both learners' rewards (:328)
+        d = done.to(torch.bool) & alive
+        final = torch.where(d, info["score"], final)
+        alive &= ~d
+        if not bool(alive.any()):
+            break
+    env.close()
+    if was_training:
+        model.train()
+    return float(ret.mean()), float(ret.std()), float((final < 0).double().mean())
+
+
 class _NullCtx:
     def __enter__(self):
         return self

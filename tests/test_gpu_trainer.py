@@ -229,3 +229,13 @@ def test_mfma_attention_backward_matches_torch(S, B):
     for name, sl in (("dq", slice(0, 32)), ("dk", slice(32, 64)), ("dv", slice(64, 96))):
         err = float((got[..., sl] - ref[..., sl]).abs().max())
         assert err <= 3e-2 * (float(ref[..., sl].abs().max()) + 1e-6), (name, err, float(ref[..., sl].abs().max()))
+
+
+def test_evaluate_vectorized_runs_and_random_policy_loses_to_baseline():
+    from pmx import mappo, trainer
+    torch.manual_seed(0)
+    model = mappo.MAPPOAgent((8, 11, 14), 5, 2).cuda()
+    mean, std, wr = trainer.evaluate_vectorized(model, layout="smallCapture", n_envs=256, opponent="baseline", length=120)
+    assert np.isfinite(mean) and np.isfinite(std) and wr < 0.2          # an untrained argmax policy does not beat the reflex bots
+    mean_r, _, wr_r = trainer.evaluate_vectorized(model, layout="smallCapture", n_envs=256, opponent="random", length=60)
+    assert np.isfinite(mean_r) and 0.0 <= wr_r <= 1.0

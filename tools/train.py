@@ -50,8 +50,8 @@ for u in range(args.updates):
                               reward=float(st["rollout_reward"]) / max(tr.N, 1), pg=f("pg"), vl=f("vl"), entropy=f("entropy"),
                               clip_frac=f("clip_frac"), grad_norm=f("grad_norm"), steps=st["optimizer_steps"])), flush=True)
         if args.eval_every and u and u % args.eval_every == 0:
-            tr.model.load_state_dict(tr.model.state_dict())
-            print(json.dumps(dict(update=u, eval=trainer.evaluate_vs_bots(tr.model, 4, args.layout, device=f"cuda:{local}"))), flush=True)
+            print(json.dumps(dict(update=u, eval_vs_baseline=trainer.evaluate_vectorized(tr.model, args.layout, 1024, "baseline", device=f"cuda:{local}"),
+                                  eval_vs_random=trainer.evaluate_vectorized(tr.model, args.layout, 1024, "random", device=f"cuda:{local}"))), flush=True)
 if rank == 0 and args.save:
     tr.save_ema(args.save)
 if world > 1:
