@@ -628,7 +628,7 @@ __device__ __forceinline__ void stream_or_row(uint32_t *T, uint32_t off, uint32_
 //      32-bit word), expands it and issues one non-temporal dwordx4 store: the wave writes 1 KiB of consecutive
 //      addresses per instruction.  LDS operations of one wavefront execute in order, so no barrier is needed.
 // ---------------------------------------------------------------------------------------------------------------
-template <int DT, bool NT, int NPW>
+template <int DT, bool NT>
 __global__ __launch_bounds__(PMX_BLOCK) void pmx_expand_kernel(PmxExpandParams p)
 {
     constexpr int VEC = ObsVec<DT>::VEC;
@@ -643,86 +643,68 @@ __global__ __launch_bounds__(PMX_BLOCK) void pmx_expand_kernel(PmxExpandParams p
         // XCD-aware order: blocks b, b+8, b+16, .. share an XCD and its L2.  Give each XCD 16 consecutive envs, i.e. the
         // envs whose SoA snapshot words share 64-byte lines, so that a line is fetched into one L2 instead of eight
         // (PMC: FETCH_SIZE per launch drops accordingly; wall time is unchanged, the kernel is store-bound).
-        // With NPW env-agents per wavefront a block covers NPW consecutive envs and the group shrinks accordingly.
-        constexpr int GS = 128 / NPW, PER = 16 / NPW;
-        const long g = blk / GS, r = blk % GS;
-        blk = g * GS + (r & 7) * PER + (r >> 3);
+        const long g = blk >> 7, r = blk & 127;
+        blk = (g << 7) + ((r & 7) << 4) + (r >> 3);
     }
+    const long q = blk * 4 + wave;
+    if (q >= total) return;
+    const long env = q / p.n_emit;
+    const int slot = (int)(q - env * p.n_emit);
+    const int agent = p.single_agent >= 0 ? p.single_agent : p.emit[slot];
+    const uint32_t *S = p.snap[agent] + env;
     const size_t N = (size_t)p.N;
     uint32_t *T = tab[wave];
+    const PmxLayoutDev *L = p.lay + (p.layout_idx ? p.layout_idx[env] : 0);
+
+    // issue the snapshot loads first, their latency hides behind the table initialisation
+    const uint32_t food = lane < H ? S[(size_t)lane * N] : 0u;
+    uint32_t pt = 0;
+    if (lane < 4) pt = S[(size_t)PMX_W_AGENT_A(H, lane) * N];
+    else if (lane < 8) pt = S[(size_t)PMX_W_CAPS(H, (lane - 4) >> 1) * N];
+    const uint32_t a_self = S[(size_t)PMX_W_AGENT_A(H, agent) * N];
+    const uint32_t b_self = S[(size_t)PMX_W_AGENT_B(H, agent) * N];
+
     const int n_words = (8 * HW + 31) >> 5;
     const int wall_words = (HW + 31) >> 5;
-    const int n_vec = 8 * HW / VEC;
-
-    // NPW (env, agent) blocks per wavefront; all snapshot loads are issued before the first table is built, so the
-    // second block's load latency hides behind the first block's stores
-    long q[NPW];
-    bool act[NPW];
-    uint32_t food[NPW], pt[NPW], a_self[NPW], b_self[NPW];
-    const PmxLayoutDev *L[NPW];
-    int agent[NPW];
-#pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-        q[i] = (blk * NPW + i) * 4 + wave;
-        act[i] = q[i] < total;
-        const long env = act[i] ? q[i] / p.n_emit : 0;
-        const int slot = act[i] ? (int)(q[i] - env * p.n_emit) : 0;
-        agent[i] = p.single_agent >= 0 ? p.single_agent : p.emit[slot];
-        const uint32_t *S = p.snap[agent[i]] + env;
-        L[i] = p.lay + (p.layout_idx ? p.layout_idx[env] : 0);
-        food[i] = (act[i] && lane < H) ? S[(size_t)lane * N] : 0u;
-        pt[i] = 0;
-        if (act[i] && lane < 4) pt[i] = S[(size_t)PMX_W_AGENT_A(H, lane) * N];
-        else if (act[i] && lane < 8) pt[i] = S[(size_t)PMX_W_CAPS(H, (lane - 4) >> 1) * N];
-        a_self[i] = act[i] ? S[(size_t)PMX_W_AGENT_A(H, agent[i]) * N] : 0u;
-        b_self[i] = act[i] ? S[(size_t)PMX_W_AGENT_B(H, agent[i]) * N] : 0u;
+    for (int k = lane; k < n_words + 1; k += 64) T[k] = k < wall_words ? L->wall_stream[k] : 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < H) {
+        stream_or_row(T, (uint32_t)((6 * H + lane) * W), food & L->hi_mask, W);    // blue food: x >= int(W/2) (capture.py:336)
+        stream_or_row(T, (uint32_t)((7 * H + lane) * W), food & L->lo_mask, W);    // red food
     }
-#pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-        if (!act[i]) continue;
-        for (int k = lane; k < n_words + 1; k += 64) T[k] = k < wall_words ? L[i]->wall_stream[k] : 0u;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lane < H) {
-            stream_or_row(T, (uint32_t)((6 * H + lane) * W), food[i] & L[i]->hi_mask, W);    // blue food: x >= int(W/2) (capture.py:336)
-            stream_or_row(T, (uint32_t)((7 * H + lane) * W), food[i] & L[i]->lo_mask, W);    // red food
-        }
-        if (lane < 4) {
-            const int x = pt[i] & 0xFF, y = (pt[i] >> 8) & 0xFF;
-            const int plane = lane == agent[i] ? 1 : (((lane ^ agent[i]) == 2) ? 4 : 5);      // gymPacMan.py:205-215
+    if (lane < 4) {
+        const int x = pt & 0xFF, y = (pt >> 8) & 0xFF;
+        const int plane = lane == agent ? 1 : (((lane ^ agent) == 2) ? 4 : 5);      // gymPacMan.py:205-215
+        const uint32_t off = (uint32_t)((plane * H + y) * W + x);
+        atomicOr(&T[off >> 5], 1u << (off & 31));
+    } else if (lane < 8) {
+        const uint32_t cxy = (pt >> (16 * ((lane - 4) & 1))) & 0xFFFFu;
+        if (cxy != 0xFFFFu) {
+            const int x = cxy & 0xFF, y = cxy >> 8;
+            const int plane = (2 * x > W) ? 2 : 3;                                  // halfList: blue x > W/2, red x <= W/2
             const uint32_t off = (uint32_t)((plane * H + y) * W + x);
             atomicOr(&T[off >> 5], 1u << (off & 31));
-        } else if (lane < 8) {
-            const uint32_t cxy = (pt[i] >> (16 * ((lane - 4) & 1))) & 0xFFFFu;
-            if (cxy != 0xFFFFu) {
-                const int x = cxy & 0xFF, y = cxy >> 8;
-                const int plane = (2 * x > W) ? 2 : 3;                                  // halfList: blue x > W/2, red x <= W/2
-                const uint32_t off = (uint32_t)((plane * H + y) * W + x);
-                atomicOr(&T[off >> 5], 1u << (off & 31));
-            }
         }
-        const uint32_t carry = (b_self[i] >> 8) & 0xFFF;
-        const int fself = (H + (int)((a_self[i] >> 8) & 0xFF)) * W + (int)(a_self[i] & 0xFF);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+    }
+    const uint32_t carry = (b_self >> 8) & 0xFFF;
+    const int fself = (H + (int)((a_self >> 8) & 0xFF)) * W + (int)(a_self & 0xFF);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
-        uint4 *out = reinterpret_cast<uint4 *>(p.obs) + (size_t)q[i] * n_vec;
-        for (int k = lane; k < n_vec; k += 64) {
-            const uint32_t e0 = (uint32_t)k * VEC;
-            const uint32_t bits = T[e0 >> 5] >> (e0 & 31);
-            uint4 v = pack_obs<DT>(bits);
-            const uint32_t d = (uint32_t)(fself - (int)e0);
-            if (d < (uint32_t)VEC) patch_self<DT>(v, (int)d, carry);
-            if (NT) {   // streaming stores (merged into one dwordx4 nt): used when the planes exceed the Infinity Cache
-                __builtin_nontemporal_store(v.x, &out[k].x); __builtin_nontemporal_store(v.y, &out[k].y);
-                __builtin_nontemporal_store(v.z, &out[k].z); __builtin_nontemporal_store(v.w, &out[k].w);
-            } else {
-                out[k] = v;
-            }
-        }
-        if (NPW > 1) {   // the next block rewrites T: all reads of this one must have been issued (in-order LDS) -- compiler fence
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+    const int n_vec = 8 * HW / VEC;
+    uint4 *out = reinterpret_cast<uint4 *>(p.obs) + (size_t)q * n_vec;
+    for (int k = lane; k < n_vec; k += 64) {
+        const uint32_t e0 = (uint32_t)k * VEC;
+        const uint32_t bits = T[e0 >> 5] >> (e0 & 31);
+        uint4 v = pack_obs<DT>(bits);
+        const uint32_t d = (uint32_t)(fself - (int)e0);
+        if (d < (uint32_t)VEC) patch_self<DT>(v, (int)d, carry);
+        if (NT) {   // streaming stores (merged into one dwordx4 nt): used when the planes exceed the Infinity Cache
+            __builtin_nontemporal_store(v.x, &out[k].x); __builtin_nontemporal_store(v.y, &out[k].y);
+            __builtin_nontemporal_store(v.z, &out[k].z); __builtin_nontemporal_store(v.w, &out[k].w);
+        } else {
+            out[k] = v;
         }
     }
 }
@@ -767,6 +749,7 @@ extern "C" hipError_t pmx_launch_reset(const PmxTickParams *p, int H, hipStream_
 extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, int dtype, hipStream_t st)
 {
     const long waves = (long)p->N * p->n_emit;
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
     // Store policy, measured in one process with tools/ab_expand.py (us per launch, ordinary / non-temporal stores):
     //   f32   323 MB 56.7/64.7   646 MB 117/126    969 MB 189/186   1.29 GB 262/236
     //   bf16  161 MB 31.6/35.9   323 MB 61.1/66.7  646 MB 172/124
@@ -777,19 +760,10 @@ extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, int dtype, hip
     const size_t bytes = (size_t)waves * 8 * p->lay_H * p->lay_W * elem;
     bool nt = elem == 1 || (elem == 2 && bytes > ((size_t)512 << 20)) || (elem == 4 && bytes > ((size_t)900 << 20));
     if (const char *o = getenv("PMX_EXPAND_NT")) nt = atoi(o) != 0;      // experiment override
-    int npw = 1;
-    if (const char *o = getenv("PMX_EXPAND_NPW")) npw = atoi(o) == 2 ? 2 : 1;   // experiment: env-agent blocks per wavefront
-    if (p->n_emit != 4 || (p->N & 127)) npw = 1;
-    const unsigned blocks = (unsigned)((waves + 4 * npw - 1) / (4 * npw));
-#define PMX_EXPAND_LAUNCH(DT)                                                                                   \
-    do {                                                                                                        \
-        if (npw == 2) {                                                                                         \
-            if (nt) hipLaunchKernelGGL((pmx_expand_kernel<DT, true, 2>), dim3(blocks), dim3(PMX_BLOCK), 0, st, *p);  \
-            else hipLaunchKernelGGL((pmx_expand_kernel<DT, false, 2>), dim3(blocks), dim3(PMX_BLOCK), 0, st, *p);    \
-        } else {                                                                                                \
-            if (nt) hipLaunchKernelGGL((pmx_expand_kernel<DT, true, 1>), dim3(blocks), dim3(PMX_BLOCK), 0, st, *p);  \
-            else hipLaunchKernelGGL((pmx_expand_kernel<DT, false, 1>), dim3(blocks), dim3(PMX_BLOCK), 0, st, *p);    \
-        }                                                                                                       \
+#define PMX_EXPAND_LAUNCH(DT)                                                                              \
+    do {                                                                                                   \
+        if (nt) hipLaunchKernelGGL((pmx_expand_kernel<DT, true>), dim3(blocks), dim3(PMX_BLOCK), 0, st, *p); \
+        else hipLaunchKernelGGL((pmx_expand_kernel<DT, false>), dim3(blocks), dim3(PMX_BLOCK), 0, st, *p);   \
     } while (0)
     switch (dtype) {
     case 0: PMX_EXPAND_LAUNCH(0); break;
