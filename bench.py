@@ -42,7 +42,17 @@ def algorithmic_bytes(H, W, e, n_obs=4):
     return 2 * S + 41 + n_obs * 8 * H * W * e
 
 
-def cpu_baseline(layout_rows, length, seconds=12.0):
+def reference_ratio(layname):
+    """port / reference speed ratio measured in the build container by tools/time_reference.py (the reference cannot
+    travel to the GPU box); None when the layout was not timed."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_cpu_reference_ratio.json")) as f:
+            return json.load(f)["layouts"][layname]["ratio_port_over_reference_1core"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def cpu_baseline(layout_rows, length, seconds=12.0, layname=None):
     """Times the oracle port on ONE host core on a bounded sample of the same workload (256 envs, f32 planes)."""
     from oracle import oracle as O
     n = 256
@@ -61,7 +71,12 @@ def cpu_baseline(layout_rows, length, seconds=12.0):
         if time.perf_counter() - t0 > seconds:
             break
     dt = time.perf_counter() - t0
-    return {"value": n * ticks / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+    ratio = reference_ratio(layname)
+    derived = {} if ratio is None else {
+        "reference_equiv_derived": n * ticks / dt / ratio,
+        "derived_note": f"port figure / {ratio:.0f} = the port-to-reference speed ratio on one core of the build container "
+                        "(tools/time_reference.py, profiles/r01_cpu_reference_ratio.json); derived, not measured here"}
+    return {"value": n * ticks / dt, "unit": "env-steps/s", "cores": 1, "kind": "port", **derived,
             "sample": f"{n} envs x {ticks} ticks of the same layout, float32 planes, auto-reset, uniform random actions "
                       f"({dt:.1f} s on 1 of {os.cpu_count()} host cores)"}
 
@@ -227,7 +242,7 @@ def main():
             "obs_checksum": checksum,
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(lay[0].text if isinstance(lay, list) else lay.text, length)
+            line["cpu_baseline"] = cpu_baseline(lay[0].text if isinstance(lay, list) else lay.text, length, layname=layname)
     env.close()
     ppo = None
     if world == 1 and not args.no_ppo and layname != "mazeGenerator":
