@@ -81,18 +81,39 @@ def cpu_baseline(layout_rows, length, seconds=12.0, layname=None):
                       f"({dt:.1f} s on 1 of {os.cpu_count()} host cores)"}
 
 
-def ppo_probe(layname, dev):
+def ppo_probe(layname, dev, rank=0, world=1, dist=None):
     """The second half of BASELINE.json's metric, measured briefly: MAPPO rollout (env tick + policy inference + shaping)
-    and PPO optimizer steps at the reference's minibatch of 512 samples (pacman_mappo_resnet.py:18), bf16 autocast."""
+    and PPO optimizer steps at the reference's minibatch of 512 samples PER GPU (pacman_mappo_resnet.py:18), bf16 autocast.
+    With more than one rank every optimizer step all-reduces the flat fp32 gradient bucket over RCCL; times are
+    bracketed by barriers and the maximum over ranks is reported, rates are whole-job."""
     from pmx import trainer
     n_envs, horizon, mb, steps = 4096, 8, 512, 40
-    tr = trainer.VecMAPPOTrainer(layname, n_envs, horizon=horizon, minibatch=mb, obs_dtype="bfloat16", device=dev, opponent="random")
+    force_pg = dist is not None and (world > 1 or os.environ.get("PMX_BENCH_FORCE_DP") == "1")
+    tr = trainer.VecMAPPOTrainer(layname, n_envs, horizon=horizon, minibatch=mb, obs_dtype="bfloat16", device=dev, opponent="random",
+                                 rank=rank, world_size=world, process_group=dist.group.WORLD if force_pg else None)
+    if force_pg and world == 1:
+        tr.learner.world_size = 2          # rehearsal on a one-GPU box: issue the RCCL all-reduce although there is one rank
+        tr.learner.pg = dist.group.WORLD
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    def tmax(dt):
+        if dist is None:
+            return dt
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     tr.rollout(); tr.compute_gae()                       # warm-up: MIOpen solver search, allocator
-    torch.cuda.synchronize(dev)
+    fence()
     t0 = time.perf_counter()
     tr.rollout(); tr.compute_gae()
-    torch.cuda.synchronize(dev)
-    t_roll = time.perf_counter() - t0
+    fence()
+    t_roll = tmax(time.perf_counter() - t0)
     S = tr.T * tr.N * 2
     obs = tr.obs_buf.view((S,) + tr.obs_shape)
     merged = tr.merged_buf.view((tr.T * tr.N,) + tr.obs_shape)
@@ -104,18 +125,23 @@ def ppo_probe(layname, dev):
                                           tr.adv_buf.view(S)[i], tr.ret_buf.view(S)[i])
     for k in range(5):
         step(k)
-    torch.cuda.synchronize(dev)
+    fence()
     t0 = time.perf_counter()
     for k in range(5, 5 + steps):
         step(k)
-    torch.cuda.synchronize(dev)
-    t_upd = time.perf_counter() - t0
+    fence()
+    t_upd = tmax(time.perf_counter() - t0)
+    grad_bytes = tr.learner.bucket.grad.numel() * 4
     tr.env.close()
-    return {"optimizer_steps_per_s": steps / t_upd, "samples_per_optimizer_step": mb, "train_samples_per_s": steps * mb / t_upd,
-            "rollout_env_steps_per_s": n_envs * horizon / t_roll, "rollout_envs": n_envs, "horizon": horizon,
+    return {"optimizer_steps_per_s": steps / t_upd, "samples_per_optimizer_step": mb * world, "samples_per_gpu_per_step": mb,
+            "train_samples_per_s": steps * mb * world / t_upd,
+            "rollout_env_steps_per_s": n_envs * horizon * world / t_roll, "rollout_envs": n_envs * world, "horizon": horizon,
+            "grad_allreduce": (f"one RCCL all-reduce of the flat fp32 gradient bucket ({grad_bytes / 1e6:.1f} MB) per optimizer step"
+                               if (world > 1 or force_pg) else "none (1 GPU)"),
             "network": "MAPPOAgent (ResNet actor + transformer critic), bf16 autocast; MIOpen NHWC convolutions + hipBLASLt + hand-written "
                        "HIP attention (MFMA), add+LayerNorm and GroupNorm+GELU kernels",
-            "reference_cpu": "about 0.5 optimizer-steps/s and 25 env-steps/s end to end on 8 host cores (SURVEY section 6)"}
+            "reference_cpu": "0.49 s per optimizer step (2 steps/s) and about 80 env-steps/s end to end on 8 host cores, smallCapture "
+                             "(tools/time_reference.py, profiles/r01_cpu_reference_ratio.json)"}
 
 
 def main():
@@ -127,7 +153,7 @@ def main():
     ap.add_argument("--envs", type=int, default=0, help="override envs per GPU")
     ap.add_argument("--obs", default="float32", choices=sorted(ELEM))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-ppo", action="store_true", help="skip the short MAPPO rollout/update probe (N=1 only)")
+    ap.add_argument("--no-ppo", action="store_true", help="skip the short MAPPO rollout/update probe")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -245,8 +271,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(lay[0].text if isinstance(lay, list) else lay.text, length, layname=layname)
     env.close()
     ppo = None
-    if world == 1 and not args.no_ppo and layname != "mazeGenerator":
-        ppo = ppo_probe(layname, dev)
+    if not args.no_ppo and layname != "mazeGenerator":
+        ppo = ppo_probe(layname, dev, rank, world, dist)
     if rank == 0:
         if ppo is not None:
             line["ppo"] = ppo
