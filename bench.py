@@ -20,6 +20,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")    # before HIP initialises: see pacman-marl-2025_amd/__init__.py
+
 import numpy as np
 import torch
 
@@ -132,8 +134,31 @@ def ppo_probe(layname, dev, rank=0, world=1, dist=None):
     fence()
     t_upd = tmax(time.perf_counter() - t0)
     grad_bytes = tr.learner.bucket.grad.numel() * 4
+    graph_rate = None
+    if world == 1 and not force_pg:
+        # the same 512-sample step replayed from a hipGraph (one GPU only: the captured RCCL all-reduce is not validated)
+        try:
+            tr.learner.capture(mb, tr.obs_shape, torch.bfloat16)
+            i0 = perm[:mb]
+            args_ = (tr._net_in(obs[i0]), tr._net_in(merged[i0 // 2]), tr.act_buf.view(S)[i0], tr.logp_buf.view(S)[i0],
+                     tr.adv_buf.view(S)[i0], tr.ret_buf.view(S)[i0])
+            for _ in range(5):
+                tr.learner.update_minibatch_graph(*args_)
+            fence()
+            t0 = time.perf_counter()
+            for k in range(5, 5 + steps):
+                i = perm[k * mb:(k + 1) * mb]
+                st = tr.learner.update_minibatch_graph(tr._net_in(obs[i]), tr._net_in(merged[i // 2]), tr.act_buf.view(S)[i],
+                                                       tr.logp_buf.view(S)[i], tr.adv_buf.view(S)[i], tr.ret_buf.view(S)[i])
+            fence()
+            graph_rate = steps / (time.perf_counter() - t0)
+            if not bool(torch.isfinite(st["grad_norm"]).item()):
+                graph_rate = "non-finite gradient norm"
+        except Exception as e:                      # the probe is optional: report, do not lose the bench line
+            graph_rate = f"failed: {type(e).__name__}: {e}"
     tr.env.close()
-    return {"optimizer_steps_per_s": steps / t_upd, "samples_per_optimizer_step": mb * world, "samples_per_gpu_per_step": mb,
+    return {"optimizer_steps_per_s": steps / t_upd, "optimizer_steps_per_s_hipgraph": graph_rate,
+            "samples_per_optimizer_step": mb * world, "samples_per_gpu_per_step": mb,
             "train_samples_per_s": steps * mb * world / t_upd,
             "rollout_env_steps_per_s": n_envs * horizon * world / t_roll, "rollout_envs": n_envs * world, "horizon": horizon,
             "grad_allreduce": (f"one RCCL all-reduce of the flat fp32 gradient bucket ({grad_bytes / 1e6:.1f} MB) per optimizer step"

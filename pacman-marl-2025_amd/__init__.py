@@ -2,6 +2,15 @@
 
 The directory is named after the reference repository (`pacman-marl-2025_amd`); import it as `pmx` (alias package at
 the repo root)."""
+import os as _os
+
+# ROCm 7's hipGraph "AQL packet capture" fast path corrupts one kernel node of a long graph after a few hundred replays
+# that are interleaved with ordinary launches (found with tools/graph_debug.py: the 233rd replay of the optimizer-step
+# graph returns a non-finite bias gradient; eager and DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 runs are clean, DESIGN.md
+# section 5).  The runtime reads the switch when HIP initialises, so it is set here, before this package touches the
+# GPU; a process that initialised HIP earlier must export it itself (mappo.graph_replay_safe() checks the variable).
+_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 from . import _lib
 from ._lib import PmxError
 from .layout import Layout, get_layout

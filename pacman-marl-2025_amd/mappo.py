@@ -122,6 +122,9 @@ def attention8(qkv):
     return _Attention8.apply(qkv)
 
 
+_DEBUG_KEEP = None    # tools/graph_debug.py: keeps (grad_out, bias_grad, weight_grad) of every token_linear backward alive
+
+
 class _TokenLinear(torch.autograd.Function):
     """F.linear on a token tensor [S, B, in] with the weight gradient computed as S batched GEMMs of depth B followed by
     a sum over S.  hipBLASLt's choice for the flat [S*B, in]^T x [S*B, out] product (K = 630 k rows, a 32 x 128 result)
@@ -138,6 +141,8 @@ class _TokenLinear(torch.autograd.Function):
         gx = gy.matmul(weight.to(gy.dtype)) if ctx.needs_input_grad[0] else None
         gw = torch.bmm(gy.transpose(1, 2), x.to(gy.dtype)).sum(0).to(weight.dtype) if ctx.needs_input_grad[1] else None
         gb = gy.sum((0, 1)).to(weight.dtype) if ctx.needs_input_grad[2] else None
+        if _DEBUG_KEEP is not None:
+            _DEBUG_KEEP.append((gy, gb, gw))
         return gx, gw, gb
 
 
@@ -455,10 +460,19 @@ class PPOLearner:
         return stats
 
     # ---- hipGraph capture of the whole optimizer step (launch-bound at the reference's minibatch of 512) ----------
+    @staticmethod
+    def graph_replay_safe():
+        """hipGraph replay is only trusted with ROCclr's AQL packet capture switched off (see the package __init__)."""
+        import os
+        return os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
+
     def capture(self, batch, obs_shape, in_dtype, clip_eps=CLIP_EPS, ent_coef=ENT_COEF_START):
         """Record zero_grad -> forward -> backward -> (all-reduce) -> clip -> Adam -> EMA for a fixed minibatch shape into
         a HIP graph.  Scalars that change between updates (lr, clip, entropy coefficient, Adam bias corrections) live in
         device tensors that the graph reads, so one capture serves the whole schedule."""
+        if not self.graph_replay_safe():
+            raise RuntimeError("hipGraph replay of the optimizer step needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment "
+                               "before HIP initialises (ROCm 7 graph packet-capture bug, DESIGN.md section 5)")
         dev = self.bucket.data.device
         self._g_in = dict(obs=torch.zeros((batch,) + tuple(obs_shape), dtype=in_dtype, device=dev),
                           merged=torch.zeros((batch,) + tuple(obs_shape), dtype=in_dtype, device=dev),
@@ -485,7 +499,8 @@ class PPOLearner:
                 import torch.distributed as dist
                 dist.all_reduce(self.bucket.grad, op=dist.ReduceOp.SUM, group=self.pg)
                 self.bucket.grad.div_(self.world_size)
-            gn = torch.linalg.vector_norm(torch.stack(torch._foreach_norm([p.grad for p in self.bucket.params])))
+            self._g_norms = torch.stack(torch._foreach_norm([p.grad for p in self.bucket.params]))   # kept: per-tensor norms
+            gn = torch.linalg.vector_norm(self._g_norms)
             self.bucket.grad.mul_(torch.clamp(MAX_GRAD_NORM / (gn + 1e-6), max=1.0))
             b1, b2 = self.betas
             g, p = self.bucket.grad, self.bucket.data

@@ -105,11 +105,14 @@ class VecMAPPOTrainer:
         self.prev_agent = self.start_words[None].expand(N, 4).clone()
         self.update_idx = 0
         self.stats = {}
-        # Optional: replay the optimizer step from a hipGraph when every minibatch has the same shape.  Off by default: with
-        # bf16 autocast the replayed step intermittently produced a non-finite gradient norm on some boxes (never in
-        # fp32, never eagerly; root cause not found yet -- DESIGN.md section 5), and a training loop must not be flaky.
-        if use_graph and use_autocast:
-            raise ValueError("hipGraph replay of the optimizer step is only supported without bf16 autocast (see DESIGN.md section 5)")
+        # Optional: replay the optimizer step from a hipGraph when every minibatch has the same shape (launch-bound at the
+        # reference's 512 samples: 1.4x more optimizer steps/s).  Needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (set by the package
+        # on import; ROCm 7's graph packet capture corrupts a node after ~230 interleaved replays); the
+        # update loop also checks the gradient norm once per update so that a non-finite policy is never sampled from.
+        if use_graph and world_size > 1:
+            raise ValueError("use_graph is validated on one GPU only (the RCCL all-reduce inside a captured graph is not)")
+        if use_graph and not mappo.PPOLearner.graph_replay_safe():
+            raise ValueError("use_graph needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 exported before HIP initialises (DESIGN.md section 5)")
         self.use_graph = bool(use_graph) and (horizon * n_envs * 2) % minibatch == 0
         self._graph_ready = False
 
@@ -241,6 +244,8 @@ class VecMAPPOTrainer:
                 steps += 1
                 agg = {k: v.clone() for k, v in st.items()} if agg is None else {k: agg[k] + st[k] for k in agg}
         self.stats.update({k: v / steps for k, v in agg.items()})
+        if self.use_graph and not bool(torch.isfinite(self.stats["grad_norm"]).item()):
+            raise RuntimeError("non-finite gradient norm from the graph-replayed optimizer step")
         self.stats.update(lr=lr, ent_coef=ent_coef, clip_eps=clip_eps, optimizer_steps=steps)
         if self.update_idx % OPPONENT_UPDATE_FREQ == 0:
             self.opponent_pool.append(self.learner.ema_state_dict())

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# must be in the environment before HIP initialises (see pacman-marl-2025_amd/__init__.py): hipGraph replays are only
+# trusted with ROCclr's graph packet capture off
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

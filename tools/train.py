@@ -7,6 +7,7 @@
 Every rank owns its env shard, rollout buffers, GAE and minibatch sampling; the only exchange is one flat-gradient
 all-reduce per optimizer step over RCCL (pmx.mappo.PPOLearner)."""
 import argparse, json, os, sys, time
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")    # before HIP initialises: see pacman-marl-2025_amd/__init__.py
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -24,6 +25,7 @@ ap.add_argument("--algorithm", default="mappo", choices=["mappo", "ippo"])
 ap.add_argument("--eval-every", type=int, default=0)
 ap.add_argument("--save", default="")
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--graph", action="store_true", help="replay the optimizer step from a hipGraph (launch-bound minibatches, e.g. 512)")
 args = ap.parse_args()
 
 rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
@@ -37,7 +39,7 @@ from pmx import trainer
 
 tr = trainer.VecMAPPOTrainer(args.layout, args.envs, horizon=args.horizon, minibatch=args.minibatch, epochs=args.epochs,
                              obs_dtype=args.obs, device=f"cuda:{local}", seed=args.seed, rank=rank, world_size=world,
-                             total_updates=args.total_updates, opponent=args.opponent, algorithm=args.algorithm)
+                             total_updates=args.total_updates, opponent=args.opponent, algorithm=args.algorithm, use_graph=args.graph)
 for u in range(args.updates):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     st = tr.train_update()
