@@ -32,7 +32,8 @@ WORKLOADS = {
     "small16384": ("smallCapture", 16384),   # BASELINE.json configs[2]: the layout the metric is quoted on
     "tiny4096": ("tinyCapture", 4096),       # configs[1]
     "blox4096": ("bloxCapture", 4096),       # the layout the reference actually trains on (20x20)
-    "mazes4096": ("mazeGenerator", 4096),    # configs[4] in miniature: per-env generated 20x20 mazes (256 distinct, cycled)
+    "mazes4096": ("mazeGenerator", 4096),    # configs[4] in miniature: every env its own generated 20x20 maze
+    "mazes8192": ("mazeGenerator", 8192),    # configs[4] per GPU: 65 536 envs on 8 GPUs, seeds 1..65536 (rank r: r*8192+1 ..)
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy ceiling)
 ELEM = {"float32": 4, "bfloat16": 2, "uint8": 1}
@@ -201,7 +202,8 @@ def main():
         n_envs = args.envs
     if layname == "mazeGenerator":
         from pmx import maze_generator
-        lay = [pmx.Layout.from_text(maze_generator.generate_maze(seed)) for seed in range(1, 257)]
+        # one distinct maze per env, the reference generator's seeds 1..N*world; about 1 ms each on the host
+        lay = [pmx.Layout.from_text(maze_generator.generate_maze(seed)) for seed in range(rank * n_envs + 1, (rank + 1) * n_envs + 1)]
         H, W = lay[0].height, lay[0].width
     else:
         lay = pmx.get_layout(layname)

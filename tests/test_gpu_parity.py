@@ -419,6 +419,31 @@ def test_per_env_layouts_vs_oracle():
     env.close()
 
 
+def test_one_distinct_maze_per_env_vs_oracle():
+    """BASELINE config 5's shape: as many distinct generated mazes as envs (seeds 1..1024), one env each."""
+    pmx = _pmx()
+    from pmx import maze_generator as MG
+    N, T = 1024, 150
+    rows = [MG.generate_maze(seed).split("\n") for seed in range(1, N + 1)]
+    lays = [pmx.Layout.from_text(r) for r in rows]
+    index = np.arange(N, dtype=np.int32)
+    env = pmx.PmxVecEnv(lays, N, length=60, auto_reset=True, obs_dtype="uint8", seed=11, layout_index=index)
+    orc = O.MultiBatchEnv(rows, index, length=60, auto_reset=True, seed=11)
+    env.reset()
+    oobs = np.zeros((N, 4, 8, 20, 20), np.float32)
+    rng = np.random.RandomState(4)
+    for t in range(T):
+        a = rng.randint(0, 5, size=(N, 4)).astype(np.int8)
+        a[rng.rand(N, 4) < 0.6] = -2
+        orc.tick(a, oobs)
+        obs, rew, done, info = env.step(torch.tensor(a).cuda())
+        assert rew.cpu().numpy().tobytes() == orc.reward.tobytes(), t
+        assert (done.cpu().numpy() == orc.done).all() and (info["legal_actions"].cpu().numpy() == orc.legal).all(), t
+        bad = np.nonzero((obs.cpu().numpy() != oobs.astype(np.uint8)).reshape(N, -1).any(1))[0]
+        assert len(bad) == 0, f"t={t}: obs differ for envs {bad[:8]}"
+    env.close()
+
+
 _TINY_BOARD = ["%%%%%%%%", "%1 .. 2%", "%  ..  %", "%3 .. 4%", "%%%%%%%%"]
 
 

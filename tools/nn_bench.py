@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--variants", default="base,cl")
+ap.add_argument("--no-infer", action="store_true")
 args = ap.parse_args()
 H, W = 11, 14
 dev = torch.device("cuda")
@@ -61,6 +62,8 @@ def run(variant):
     for _ in range(args.steps):
         step(obs, merged, act, logp, adv, ret)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
+    if args.no_infer:
+        return dict(variant=variant, batch=B, train_ms=dt * 1e3, train_samples_per_s=B / dt)
     # inference
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         for _ in range(2):
