@@ -118,6 +118,8 @@ void fill_tick_params(pmx_env *env, PmxTickParams &p, const int8_t *actions, con
         p.agent_out = out->agent_dev;
     }
     p.seed = env->cfg.seed;
+    p.lay_W = env->lay.W; p.lay_H = env->lay.H; p.lay_half = env->lay.half; p.lay_n_dump = env->lay.n_dump;
+    p.lo_mask = env->lay.lo_mask; p.hi_mask = env->lay.hi_mask;
 }
 
 // when profiling, returns the pair of events to record around the next launch of that kernel (or nullptr)

@@ -67,6 +67,10 @@ struct PmxTickParams {
     uint32_t seed;
     const uint8_t *reset_mask;   // reset kernel only: NULL = every env
     int32_t no_reset;            // reset kernel only: 1 = touch no env (legal masks of the current state only)
+    // host-side copies of what every layout of a handle shares, so that the kernel has them with its arguments instead
+    // of behind a dependent load from the layout record
+    int32_t lay_W, lay_H, lay_half, lay_n_dump;
+    uint32_t lo_mask, hi_mask;
 };
 
 struct PmxExpandParams {

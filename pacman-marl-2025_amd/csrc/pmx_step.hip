@@ -39,6 +39,7 @@ struct Ctx {
     const PmxLayoutDev *L;
     const int8_t *dump;
     int W, H, half, n_dump;
+    uint32_t lo_mask, hi_mask;   // halfGrid column masks of this layout (loaded once, up front)
     int legal_reward, defence_reward;
     uint32_t rng_key;     // seed ^ env * 0x9E3779B1 (the per-env part of the random-legal key)
     uint32_t start_xy[4]; // start cells, packed like Env::xy
@@ -228,7 +229,7 @@ __device__ __noinline__ int bot_action(const Env &e, const Ctx &c, bool defensiv
     constexpr bool RED = (I % 2) == 0;
     constexpr int O1 = RED ? 1 : 0, O2 = O1 + 2;
     const int legal = legal_mask(c.wl, c.wls, (int)(e.xy[I] & 0xFF), (int)(e.xy[I] >> 8));
-    const uint32_t enemy_mask = RED ? c.L->hi_mask : c.L->lo_mask;      // getFood: the other side's pellets
+    const uint32_t enemy_mask = RED ? c.hi_mask : c.lo_mask;      // getFood: the other side's pellets
     int food_left = 0;
     for (int y = 0; y < c.H; ++y) food_left += __popc(c.fd[y * PMX_RULE_BLOCK] & enemy_mask);
     const int start_idx = c.cidx[(c.start_xy[I] >> 8) * 32 + (c.start_xy[I] & 0xFF)];
@@ -324,6 +325,44 @@ __device__ __forceinline__ void tick_substep(Env &e, Acc &a, const Ctx &c, int a
     e.self_after[I] = e.xy[I] | ((uint32_t)e.carry[I] << 16);
 }
 
+// HB > 0: the board has at most HB rows and the row loops are fully unrolled with predicated accesses, so that all HBM
+// loads (or all LDS reads) of a state are in flight at once.  With a run-time trip count the compiler emits
+// load -> s_waitcnt -> ds_write per row: H dependent memory round trips on a kernel that runs one wave per SIMD.
+// The run-time loops remain for the per-agent and query kernels, which are not on the hot path.
+struct RawEnv {            // the non-row state words as loaded, before unpacking
+    uint32_t a[4], b[4], capw[2], score, steps, ticks;
+};
+// phase 1 of the hot-path load: nothing but global loads (needs only the kernel arguments), issued before the layout
+// set-up so that the HBM latency overlaps it
+template <int HB>
+__device__ __forceinline__ void load_env_issue(RawEnv &r, uint32_t (&rows)[HB], const uint32_t *st, int N, int env, int H)
+{
+#pragma unroll
+    for (int y = 0; y < HB; ++y) rows[y] = y < H ? st[(size_t)y * N + env] : 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        r.a[i] = st[(size_t)PMX_W_AGENT_A(H, i) * N + env];
+        r.b[i] = st[(size_t)PMX_W_AGENT_B(H, i) * N + env];
+    }
+    r.capw[0] = st[(size_t)PMX_W_CAPS(H, 0) * N + env];
+    r.capw[1] = st[(size_t)PMX_W_CAPS(H, 1) * N + env];
+    r.score = st[(size_t)PMX_W_SCORE(H) * N + env];
+    r.steps = st[(size_t)PMX_W_STEPS(H) * N + env];
+    r.ticks = st[(size_t)PMX_W_TICKS(H) * N + env];
+}
+// phase 2: unpack into registers, food rows into this lane's LDS column
+template <int HB>
+__device__ __forceinline__ void load_env_commit(Env &e, const Ctx &c, const RawEnv &r, const uint32_t (&rows)[HB])
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { unpack_a(e, i, r.a[i]); unpack_b(e, i, r.b[i]); }
+    e.capw[0] = r.capw[0]; e.capw[1] = r.capw[1];
+    e.score = (int)r.score; e.steps = (int)r.steps; e.ticks = r.ticks;
+#pragma unroll
+    for (int y = 0; y < HB; ++y)
+        if (y < c.H) c.fd[y * PMX_RULE_BLOCK] = rows[y];
+}
+
 __device__ __forceinline__ void load_env(Env &e, const Ctx &c, const uint32_t *st, int N, int env)
 {
     for (int y = 0; y < c.H; ++y) c.fd[y * PMX_RULE_BLOCK] = st[(size_t)y * N + env];
@@ -338,11 +377,19 @@ __device__ __forceinline__ void load_env(Env &e, const Ctx &c, const uint32_t *s
     e.steps = (int)st[(size_t)PMX_W_STEPS(c.H) * N + env];
     e.ticks = st[(size_t)PMX_W_TICKS(c.H) * N + env];
 }
-
-// first PMX_SNAP_WORDS words (food, agents, capsules)
+template <int HB = 0>
 __device__ __forceinline__ void store_snapshot(const Env &e, const Ctx &c, uint32_t *st, int N, int env)
 {
-    for (int y = 0; y < c.H; ++y) st[(size_t)y * N + env] = c.fd[y * PMX_RULE_BLOCK];
+    if constexpr (HB > 0) {
+        uint32_t rows[HB];
+#pragma unroll
+        for (int y = 0; y < HB; ++y) rows[y] = y < c.H ? c.fd[y * PMX_RULE_BLOCK] : 0u;
+#pragma unroll
+        for (int y = 0; y < HB; ++y)
+            if (y < c.H) st[(size_t)y * N + env] = rows[y];
+    } else {
+        for (int y = 0; y < c.H; ++y) st[(size_t)y * N + env] = c.fd[y * PMX_RULE_BLOCK];
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         st[(size_t)PMX_W_AGENT_A(c.H, i) * N + env] = pack_a(e, i);
@@ -351,16 +398,14 @@ __device__ __forceinline__ void store_snapshot(const Env &e, const Ctx &c, uint3
     st[(size_t)PMX_W_CAPS(c.H, 0) * N + env] = e.capw[0];
     st[(size_t)PMX_W_CAPS(c.H, 1) * N + env] = e.capw[1];
 }
-
+template <int HB = 0>
 __device__ __forceinline__ void store_env(const Env &e, const Ctx &c, uint32_t *st, int N, int env)
 {
-    store_snapshot(e, c, st, N, env);
+    store_snapshot<HB>(e, c, st, N, env);
     st[(size_t)PMX_W_SCORE(c.H) * N + env] = (uint32_t)e.score;
     st[(size_t)PMX_W_STEPS(c.H) * N + env] = (uint32_t)e.steps;
     st[(size_t)PMX_W_TICKS(c.H) * N + env] = e.ticks;
 }
-
-// game.py:490-508 GameStateData.initialize + gymPacMan.py:94 steps = 0
 __device__ __forceinline__ void init_env(Env &e, const Ctx &c)
 {
     for (int y = 0; y < c.H; ++y) c.fd[y * PMX_RULE_BLOCK] = c.L->food0[y];
@@ -374,15 +419,25 @@ __device__ __forceinline__ void init_env(Env &e, const Ctx &c)
 }
 
 // gymPacMan.py:171-193: everything after the four sub-steps.
+template <int HB = 0>
 __device__ __forceinline__ void tick_finish(Env &e, Acc &a, const Ctx &c, const PmxTickParams &p, int env, bool fused)
 {
     double blue_r = a.blue_r + (double)(a.blue_sc > 0 ? a.blue_sc : 0);   // :171-172
     double red_r = a.red_r + (double)(a.red_sc > 0 ? a.red_sc : 0);
     int n_red = 0, n_blue = 0;                                            // capture.py:332-342 halfGrid sums
-    for (int y = 0; y < c.H; ++y) {
-        uint32_t row = c.fd[y * PMX_RULE_BLOCK];
-        n_red += __popc(row & c.L->lo_mask);
-        n_blue += __popc(row & c.L->hi_mask);
+    if constexpr (HB > 0) {
+#pragma unroll
+        for (int y = 0; y < HB; ++y) {
+            const uint32_t row = y < c.H ? c.fd[y * PMX_RULE_BLOCK] : 0u;
+            n_red += __popc(row & c.lo_mask);
+            n_blue += __popc(row & c.hi_mask);
+        }
+    } else {
+        for (int y = 0; y < c.H; ++y) {
+            uint32_t row = c.fd[y * PMX_RULE_BLOCK];
+            n_red += __popc(row & c.lo_mask);
+            n_blue += __popc(row & c.hi_mask);
+        }
     }
     bool done = (n_blue == 0 && e.carry[0] == 0 && e.carry[2] == 0) ||    // gymPacMan.py:261-270
                 (n_red == 0 && e.carry[1] == 0 && e.carry[3] == 0) || (e.steps >= p.length);
@@ -421,7 +476,7 @@ __device__ __forceinline__ Ctx make_ctx(const PmxTickParams &p, uint32_t *lds)
     const int env0 = blockIdx.x * PMX_RULE_BLOCK + threadIdx.x;
     const bool multi = p.layout_idx != nullptr;
     c.L = p.lay + ((multi && env0 < p.N) ? p.layout_idx[env0] : 0);
-    c.W = p.lay->W; c.H = p.lay->H; c.half = p.lay->half; c.n_dump = p.lay->n_dump;   // identical in every layout of a handle
+    c.W = p.lay_W; c.H = p.lay_H; c.half = p.lay_half; c.n_dump = p.lay_n_dump;       // identical in every layout of a handle
     c.dump = p.dump;
     c.legal_reward = p.legal_reward; c.defence_reward = p.defence_reward;
     c.wl = multi ? lds + 32 + PMX_MAX_H_LDS * PMX_RULE_BLOCK + threadIdx.x : lds;
@@ -431,13 +486,18 @@ __device__ __forceinline__ Ctx make_ctx(const PmxTickParams &p, uint32_t *lds)
     c.dist = p.dist ? p.dist + c.L->dist_off : nullptr;
     c.cidx = p.cell_index ? p.cell_index + (size_t)(c.L - p.lay) * 1024 : nullptr;
     c.n_cells = c.L->n_cells;
+    c.lo_mask = p.lo_mask; c.hi_mask = p.hi_mask;
 #pragma unroll
     for (int i = 0; i < 4; ++i) c.start_xy[i] = (uint32_t)c.L->startx[i] | ((uint32_t)c.L->starty[i] << 8);
     c.rng_key = p.seed ^ ((uint32_t)(blockIdx.x * PMX_RULE_BLOCK + threadIdx.x) * 0x9E3779B1u);
     if (threadIdx.x < 32) lds[threadIdx.x] = threadIdx.x < (unsigned)c.H ? p.lay->walls[threadIdx.x] : 0xFFFFFFFFu;
     if (multi) {   // per-env layouts: every lane keeps its own wall column next to its food column
         uint32_t *w = lds + 32 + PMX_MAX_H_LDS * PMX_RULE_BLOCK + threadIdx.x;
-        for (int y = 0; y < 32; ++y) w[y * PMX_RULE_BLOCK] = y < c.H ? c.L->walls[y] : 0xFFFFFFFFu;
+        uint32_t wr[32];
+#pragma unroll
+        for (int y = 0; y < 32; ++y) wr[y] = y < c.H ? c.L->walls[y] : 0xFFFFFFFFu;     // all loads in flight, then the LDS writes
+#pragma unroll
+        for (int y = 0; y < 32; ++y) w[y * PMX_RULE_BLOCK] = wr[y];
     }
     __syncthreads();
     return c;
@@ -446,27 +506,34 @@ __device__ __forceinline__ Ctx make_ctx(const PmxTickParams &p, uint32_t *lds)
 }  // namespace
 
 // dynamic LDS: 32 wall rows + H food rows x PMX_RULE_BLOCK lanes
-template <bool BOTS>
+template <bool BOTS, int HB>
 __global__ __launch_bounds__(PMX_RULE_BLOCK) void pmx_rule_kernel(PmxTickParams p)
 {
     extern __shared__ uint32_t lds[];
-    Ctx c = make_ctx(p, lds);
     const int env = blockIdx.x * PMX_RULE_BLOCK + threadIdx.x;
-    if (env >= p.N) return;
+    const bool live = env < p.N;
+    RawEnv raw;
+    uint32_t rows[HB];
+    uint32_t av = 0;
+    if (live) {
+        load_env_issue<HB>(raw, rows, p.state, p.N, env, p.lay_H);
+        av = reinterpret_cast<const uint32_t *>(p.actions)[env];   // 4 int8 actions
+    }
+    Ctx c = make_ctx(p, lds);
+    if (!live) return;
     Env e;
-    load_env(e, c, p.state, p.N, env);
+    load_env_commit<HB>(e, c, raw, rows);
     Acc a = { 0.0, 0.0, 0, 0, 0 };
-    const uint32_t av = reinterpret_cast<const uint32_t *>(p.actions)[env];   // 4 int8 actions
     const size_t snap_sz = (size_t)PMX_SNAP_WORDS(c.H) * p.N;
     tick_substep<0, BOTS>(e, a, c, (int)(int8_t)(av & 0xFF));
-    store_snapshot(e, c, p.snap, p.N, env);
+    store_snapshot<HB>(e, c, p.snap, p.N, env);
     tick_substep<1, BOTS>(e, a, c, (int)(int8_t)((av >> 8) & 0xFF));
-    store_snapshot(e, c, p.snap + snap_sz, p.N, env);
+    store_snapshot<HB>(e, c, p.snap + snap_sz, p.N, env);
     tick_substep<2, BOTS>(e, a, c, (int)(int8_t)((av >> 16) & 0xFF));
-    store_snapshot(e, c, p.snap + 2 * snap_sz, p.N, env);
+    store_snapshot<HB>(e, c, p.snap + 2 * snap_sz, p.N, env);
     tick_substep<3, BOTS>(e, a, c, (int)(int8_t)((av >> 24) & 0xFF));
-    tick_finish(e, a, c, p, env, true);
-    store_env(e, c, p.state, p.N, env);
+    tick_finish<HB>(e, a, c, p, env, true);
+    store_env<HB>(e, c, p.state, p.N, env);
 }
 
 // pmx_step_agent: one sub-step; the accumulators of the open tick travel through the state words.
@@ -716,8 +783,17 @@ extern "C" hipError_t pmx_launch_rule(const PmxTickParams *p, int H, hipStream_t
 {
     const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
     const size_t lds = (p->layout_idx ? 32 + (size_t)(2 * PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)2 * H * PMX_RULE_BLOCK) * sizeof(uint32_t);
-    if (p->dist) hipLaunchKernelGGL(pmx_rule_kernel<true>, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p);
-    else hipLaunchKernelGGL(pmx_rule_kernel<false>, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p);
+    // row loops unrolled for the board-height bucket (see load_env_issue)
+    const int hb = H <= 12 ? 12 : (H <= 16 ? 16 : (H <= 20 ? 20 : 32));
+#define PMX_RULE_LAUNCH(B, HBV) hipLaunchKernelGGL((pmx_rule_kernel<B, HBV>), dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p)
+#define PMX_RULE_PICK(B)                                                                      \
+    switch (hb) {                                                                             \
+    case 12: PMX_RULE_LAUNCH(B, 12); break;                                                   \
+    case 16: PMX_RULE_LAUNCH(B, 16); break;                                                   \
+    case 20: PMX_RULE_LAUNCH(B, 20); break;                                                   \
+    default: PMX_RULE_LAUNCH(B, 32); break;                                                   \
+    }
+    if (p->dist) { PMX_RULE_PICK(true) } else { PMX_RULE_PICK(false) }
     return hipGetLastError();
 }
 
