@@ -826,20 +826,29 @@ extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, int dtype, hip
 {
     const long waves = (long)p->N * p->n_emit;
     const unsigned blocks = (unsigned)((waves + 3) / 4);
-    // Store policy, measured in one process with tools/ab_expand.py (us per launch, ordinary / non-temporal stores):
-    //   f32   323 MB 56.7/64.7   646 MB 117/126    969 MB 189/186   1.29 GB 262/236
-    //   bf16  161 MB 31.6/35.9   323 MB 61.1/66.7  646 MB 172/124
-    //   u8     80 MB 29.6/28.5   323 MB 111/102
-    // Ordinary stores win while the 256 MiB Infinity Cache can absorb a good part of the planes; beyond that, and for
-    // the short uint8 blocks, streaming stores win.
+    // Store policy, measured in one process with tools/ab_expand.py (us per launch):
+    //   f32   323 MB  ordinary 53.7 | nt 64.9 | nt + 3 blocks/CU 60.0
+    //         646 MB  ordinary 114.6 | nt 126.1 | nt + 3 blocks/CU 107.2
+    //        1.29 GB  ordinary 262 | nt 246 | nt + 4 blocks/CU 227 | nt + 3 blocks/CU 207.8 | nt + 2 blocks/CU 278
+    //   bf16  161 MB  31.6/35.9   323 MB 61.1/66.7  646 MB 172/124 (ordinary / nt)
+    //   u8     80 MB  29.6/28.5   323 MB 111/102
+    // Ordinary stores win while the 256 MiB Infinity Cache can absorb a good part of the planes.  Beyond that, streaming
+    // (non-temporal) stores win, and they win more with FEWER wavefronts in flight: every wave is its own sequential
+    // write stream, and 12 waves per CU instead of 32 keep the number of DRAM pages open at once low enough for the
+    // write-combined bursts to stay row-buffer hits (6.2 TB/s instead of 5.3 at 1.29 GB).  The occupancy cap is an
+    // unused dynamic-LDS reservation of 40 000 bytes per block (3 blocks of 4 waves fit the 160 KB of a CU).
     const size_t elem = dtype == 0 ? 4 : (dtype == 1 ? 2 : 1);
     const size_t bytes = (size_t)waves * 8 * p->lay_H * p->lay_W * elem;
-    bool nt = elem == 1 || (elem == 2 && bytes > ((size_t)512 << 20)) || (elem == 4 && bytes > ((size_t)900 << 20));
+    // (the cap is for float32 only: the bf16 / uint8 variants are issue-bound and lose up to 2x with it; on 20x20 boards,
+    // 51 KB per wave, all four combinations are within 6 % of each other and nt + cap is never the worst)
+    bool nt = elem == 1 || bytes > ((size_t)480 << 20);
     if (const char *o = getenv("PMX_EXPAND_NT")) nt = atoi(o) != 0;      // experiment override
+    size_t lds_pad = (nt && elem == 4) ? 40000 : 0;
+    if (const char *o = getenv("PMX_EXPAND_LDS_PAD")) lds_pad = (size_t)atoi(o);   // experiment override
 #define PMX_EXPAND_LAUNCH(DT)                                                                              \
     do {                                                                                                   \
-        if (nt) hipLaunchKernelGGL((pmx_expand_kernel<DT, true>), dim3(blocks), dim3(PMX_BLOCK), 0, st, *p); \
-        else hipLaunchKernelGGL((pmx_expand_kernel<DT, false>), dim3(blocks), dim3(PMX_BLOCK), 0, st, *p);   \
+        if (nt) hipLaunchKernelGGL((pmx_expand_kernel<DT, true>), dim3(blocks), dim3(PMX_BLOCK), lds_pad, st, *p); \
+        else hipLaunchKernelGGL((pmx_expand_kernel<DT, false>), dim3(blocks), dim3(PMX_BLOCK), lds_pad, st, *p);   \
     } while (0)
     switch (dtype) {
     case 0: PMX_EXPAND_LAUNCH(0); break;
