@@ -370,6 +370,12 @@ def canonicalize_action(action, is_red_agent):
 def ppo_loss(model, obs, merged, act, old_logp, adv, ret, clip_eps, ent_coef, vf_coef=VF_COEF):
     """The minibatch objective of pacman_mappo_resnet.py:571-585.  Returns (loss, dict of detached scalars)."""
     vals, logp, ent = model.evaluate(obs, merged, act)
+    if vals.shape[0] != ret.shape[0]:
+        # paired minibatch: rows 2k and 2k+1 are the two learners of one env-tick and share ONE merged critic input
+        # (merge_obs_for_critic is per env-tick, pacman_mappo_resnet.py:556-557 expands it per agent); the critic ran on
+        # the unique inputs only and its value is used for both rows -- the same numbers, half the critic work
+        assert vals.shape[0] * 2 == ret.shape[0]
+        vals = vals.repeat_interleave(2)
     norm_adv = (adv - adv.mean()) / (adv.std() + 1e-8)                   # unbiased std, per minibatch (:577)
     ratio = (logp - old_logp).exp()
     pg = -torch.min(norm_adv * ratio, norm_adv * torch.clamp(ratio, 1 - clip_eps, 1 + clip_eps)).mean()
@@ -466,7 +472,7 @@ class PPOLearner:
         import os
         return os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
 
-    def capture(self, batch, obs_shape, in_dtype, clip_eps=CLIP_EPS, ent_coef=ENT_COEF_START):
+    def capture(self, batch, obs_shape, in_dtype, clip_eps=CLIP_EPS, ent_coef=ENT_COEF_START, merged_batch=None):
         """Record zero_grad -> forward -> backward -> (all-reduce) -> clip -> Adam -> EMA for a fixed minibatch shape into
         a HIP graph.  Scalars that change between updates (lr, clip, entropy coefficient, Adam bias corrections) live in
         device tensors that the graph reads, so one capture serves the whole schedule."""
@@ -475,7 +481,7 @@ class PPOLearner:
                                "before HIP initialises (ROCm 7 graph packet-capture bug, DESIGN.md section 5)")
         dev = self.bucket.data.device
         self._g_in = dict(obs=torch.zeros((batch,) + tuple(obs_shape), dtype=in_dtype, device=dev),
-                          merged=torch.zeros((batch,) + tuple(obs_shape), dtype=in_dtype, device=dev),
+                          merged=torch.zeros((merged_batch or batch,) + tuple(obs_shape), dtype=in_dtype, device=dev),
                           act=torch.zeros(batch, dtype=torch.int64, device=dev),
                           logp=torch.zeros(batch, dtype=torch.float32, device=dev),
                           adv=torch.randn(batch, dtype=torch.float32, device=dev),

@@ -55,7 +55,7 @@ def canonicalize_obs(o):
 class VecMAPPOTrainer:
     def __init__(self, layout, n_envs, horizon=32, minibatch=512, epochs=UPDATE_EPOCHS, obs_dtype="bfloat16",
                  device="cuda:0", seed=0, rank=0, world_size=1, process_group=None, total_updates=2000, length=300,
-                 use_autocast=True, opponent="random", use_graph=False, algorithm="mappo"):
+                 use_autocast=True, opponent="random", use_graph=False, algorithm="mappo", paired_minibatches=True):
         self.device = torch.device(device)
         self.rank, self.world_size = rank, world_size
         self.env = PmxVecEnv(layout, n_envs, length=length, reward_forLegalAction=True, defenceReward=True,
@@ -68,6 +68,12 @@ class VecMAPPOTrainer:
         # IPPO, so this variant has no parity target -- SURVEY section 0)
         assert algorithm in ("mappo", "ippo")
         self.algorithm = algorithm
+        # paired_minibatches: a minibatch is drawn as (env-tick) PAIRS, both learners of a pair together, so that the
+        # centralised critic runs once per pair instead of once per agent sample (its input is the same merged observation
+        # for both).  Every epoch is still a random permutation that visits each sample once and the loss of a minibatch is
+        # the reference's; only the composition of the minibatches differs from the reference's independent shuffle of
+        # agent samples (pacman_mappo_resnet.py:566-569).  False restores that shuffle.
+        self.paired = bool(paired_minibatches) and algorithm == "mappo" and minibatch % 2 == 0
         self.total_updates = total_updates
         H, W = self.env.layout.height, self.env.layout.width
         self.obs_shape = (8, H, W)
@@ -231,15 +237,22 @@ class VecMAPPOTrainer:
         agg = None
         steps = 0
         for _ in range(self.epochs):
-            perm = torch.randperm(S, device=self.device, generator=self.gen)
+            if self.paired:
+                pperm = torch.randperm(S // 2, device=self.device, generator=self.gen)
+            else:
+                perm = torch.randperm(S, device=self.device, generator=self.gen)
             for s0 in range(0, S, self.minibatch):
-                mb = perm[s0:s0 + self.minibatch]
+                if self.paired:
+                    pr = pperm[s0 // 2:(s0 + self.minibatch) // 2]
+                    mb = torch.stack((2 * pr, 2 * pr + 1), dim=1).reshape(-1)      # rows 2k, 2k+1 = the two learners of pair k
+                else:
+                    mb = perm[s0:s0 + self.minibatch]
                 if self.use_graph and not self._graph_ready:
                     self.learner.capture(self.minibatch, self.obs_shape, torch.bfloat16 if self.autocast_dtype is not None else torch.float32,
-                                         clip_eps, ent_coef)
+                                         clip_eps, ent_coef, merged_batch=self.minibatch // 2 if self.paired else None)
                     self._graph_ready = True
                 step = self.learner.update_minibatch_graph if self.use_graph else self.learner.update_minibatch
-                critic_in = merged[mb // 2] if self.algorithm == "mappo" else obs[mb]
+                critic_in = merged[pr] if self.paired else (merged[mb // 2] if self.algorithm == "mappo" else obs[mb])
                 st = step(self._net_in(obs[mb]), self._net_in(critic_in), act[mb], logp[mb], adv[mb], ret[mb], clip_eps, ent_coef)
                 steps += 1
                 agg = {k: v.clone() for k, v in st.items()} if agg is None else {k: agg[k] + st[k] for k in agg}

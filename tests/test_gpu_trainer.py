@@ -150,6 +150,16 @@ def test_graph_replay_bf16_stays_finite_past_230_replays():
     assert bool(torch.isfinite(L.bucket.data).all())
 
 
+def test_unpaired_minibatches_still_run():
+    """paired_minibatches=False is the reference's independent shuffle of agent samples."""
+    from pmx import trainer
+    tr = trainer.VecMAPPOTrainer("tinyCapture", 128, horizon=8, minibatch=256, obs_dtype="bfloat16", opponent="random", paired_minibatches=False)
+    assert not tr.paired
+    s = tr.train_update()
+    assert torch.isfinite(s["loss"]).all() and s["optimizer_steps"] == 3 * (8 * 128 * 2 // 256)
+    tr.env.close()
+
+
 def test_graph_trainer_bf16_updates():
     """The trainer with the graph-replayed bf16 optimizer step: three full updates stay finite and learn the same kind of
     statistics as the eager loop."""

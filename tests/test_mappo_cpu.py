@@ -164,3 +164,23 @@ def test_data_parallel_two_ranks_gloo():
         learner._adam_step()
     # thread counts (1 vs 2) change conv-backward summation order; Adam turns that into <= ~1e-2 of a 2e-4 step
     assert np.allclose(learner.bucket.data.numpy(), res[0][0], rtol=1e-4, atol=5e-6)
+
+
+def test_paired_minibatch_loss_equals_expanded_loss():
+    """ppo_loss with ONE merged critic input per env-tick pair == the reference's form with that input repeated per agent."""
+    from pmx import mappo
+    torch.manual_seed(5)
+    shape, P = (8, 7, 20), 6
+    model = mappo.MAPPOAgent(shape, 5, 2)
+    obs = (torch.rand((2 * P,) + shape) < 0.2).float()
+    merged = (torch.rand((P,) + shape) < 0.2).float()
+    act = torch.randint(0, 5, (2 * P,))
+    logp, adv, ret = -1.6 + 0.1 * torch.randn(2 * P), torch.randn(2 * P), torch.randn(2 * P)
+    la, _ = mappo.ppo_loss(model, obs, merged, act, logp, adv, ret, 0.15, 0.02)
+    ga = torch.autograd.grad(la, [p for p in model.parameters() if p.requires_grad], allow_unused=True)
+    lb, _ = mappo.ppo_loss(model, obs, merged.repeat_interleave(2, dim=0), act, logp, adv, ret, 0.15, 0.02)
+    gb = torch.autograd.grad(lb, [p for p in model.parameters() if p.requires_grad], allow_unused=True)
+    assert torch.allclose(la, lb, rtol=1e-6, atol=1e-7)
+    for x, y in zip(ga, gb):
+        if x is not None:
+            assert torch.allclose(x, y, rtol=1e-4, atol=1e-6)
