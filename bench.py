@@ -120,12 +120,16 @@ def ppo_probe(layname, dev, rank=0, world=1, dist=None):
     S = tr.T * tr.N * 2
     obs = tr.obs_buf.view((S,) + tr.obs_shape)
     merged = tr.merged_buf.view((tr.T * tr.N,) + tr.obs_shape)
-    perm = torch.randperm(S, device=dev)
+    pperm = torch.randperm(S // 2, device=dev)          # minibatches of env-tick pairs, as the trainer draws them (paired_minibatches)
+
+    def batch(k):
+        pr = pperm[k * (mb // 2):(k + 1) * (mb // 2)]
+        i = torch.stack((2 * pr, 2 * pr + 1), dim=1).reshape(-1)
+        return (tr._net_in(obs[i]), tr._net_in(merged[pr]), tr.act_buf.view(S)[i], tr.logp_buf.view(S)[i],
+                tr.adv_buf.view(S)[i], tr.ret_buf.view(S)[i])
 
     def step(k):
-        i = perm[k * mb:(k + 1) * mb]
-        tr.learner.update_minibatch(tr._net_in(obs[i]), tr._net_in(merged[i // 2]), tr.act_buf.view(S)[i], tr.logp_buf.view(S)[i],
-                                          tr.adv_buf.view(S)[i], tr.ret_buf.view(S)[i])
+        tr.learner.update_minibatch(*batch(k))
     for k in range(5):
         step(k)
     fence()
@@ -139,18 +143,13 @@ def ppo_probe(layname, dev, rank=0, world=1, dist=None):
     if world == 1 and not force_pg:
         # the same 512-sample step replayed from a hipGraph (one GPU only: the captured RCCL all-reduce is not validated)
         try:
-            tr.learner.capture(mb, tr.obs_shape, torch.bfloat16)
-            i0 = perm[:mb]
-            args_ = (tr._net_in(obs[i0]), tr._net_in(merged[i0 // 2]), tr.act_buf.view(S)[i0], tr.logp_buf.view(S)[i0],
-                     tr.adv_buf.view(S)[i0], tr.ret_buf.view(S)[i0])
-            for _ in range(5):
-                tr.learner.update_minibatch_graph(*args_)
+            tr.learner.capture(mb, tr.obs_shape, torch.bfloat16, merged_batch=mb // 2)
+            for k in range(5):
+                tr.learner.update_minibatch_graph(*batch(k))
             fence()
             t0 = time.perf_counter()
             for k in range(5, 5 + steps):
-                i = perm[k * mb:(k + 1) * mb]
-                st = tr.learner.update_minibatch_graph(tr._net_in(obs[i]), tr._net_in(merged[i // 2]), tr.act_buf.view(S)[i],
-                                                       tr.logp_buf.view(S)[i], tr.adv_buf.view(S)[i], tr.ret_buf.view(S)[i])
+                st = tr.learner.update_minibatch_graph(*batch(k))
             fence()
             graph_rate = steps / (time.perf_counter() - t0)
             if not bool(torch.isfinite(st["grad_norm"]).item()):
@@ -160,6 +159,7 @@ def ppo_probe(layname, dev, rank=0, world=1, dist=None):
     tr.env.close()
     return {"optimizer_steps_per_s": steps / t_upd, "optimizer_steps_per_s_hipgraph": graph_rate,
             "samples_per_optimizer_step": mb * world, "samples_per_gpu_per_step": mb,
+            "minibatch": "256 env-tick pairs = 512 agent samples per GPU; the centralised critic runs once per pair",
             "train_samples_per_s": steps * mb * world / t_upd,
             "rollout_env_steps_per_s": n_envs * horizon * world / t_roll, "rollout_envs": n_envs * world, "horizon": horizon,
             "grad_allreduce": (f"one RCCL all-reduce of the flat fp32 gradient bucket ({grad_bytes / 1e6:.1f} MB) per optimizer step"

@@ -52,6 +52,7 @@ class _LN32Residual(torch.autograd.Function):
         _lib.check(lib.pmx_ln32_forward(x.data_ptr(), a.data_ptr(), wf.data_ptr(), bf.data_ptr(), y.data_ptr(), mean.data_ptr(),
                                         rstd.data_ptr(), rows, float(eps), 0 if x.dtype == torch.float32 else 1, st), "pmx_ln32_forward")
         ctx.save_for_backward(x, a, wf, mean, rstd)
+        ctx.wdtype = w.dtype
         return y
 
     @staticmethod
@@ -67,7 +68,7 @@ class _LN32Residual(torch.autograd.Function):
         _lib.check(lib.pmx_ln32_backward(x.data_ptr(), a.data_ptr(), gy.data_ptr(), wf.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                          dz.data_ptr(), partial.data_ptr(), x.numel() // 32,
                                          0 if x.dtype == torch.float32 else 1, st), "pmx_ln32_backward")
-        dwb = partial.sum(0)
+        dwb = partial.sum(0).to(ctx.wdtype)          # gradients carry the dtype of the parameters they belong to
         return dz, dz, dwb[:32], dwb[32:], None
 
 
@@ -212,7 +213,7 @@ class _GN8Gelu(torch.autograd.Function):
                                                 rstd.data_ptr(), B, groups, HW, float(eps), 0 if h.dtype == torch.float32 else 1, st),
                        "pmx_gn8_gelu_forward")
         ctx.save_for_backward(h, res if res is not None else h.new_empty(0), wf, bf, mean, rstd)
-        ctx.has_res, ctx.groups, ctx.HW, ctx.cl = res is not None, groups, HW, cl
+        ctx.has_res, ctx.groups, ctx.HW, ctx.cl, ctx.wdtype = res is not None, groups, HW, cl, w.dtype
         return y
 
     @staticmethod
@@ -236,7 +237,7 @@ class _GN8Gelu(torch.autograd.Function):
             _lib.check(lib.pmx_gn8_gelu_backward(h.data_ptr(), rp, gy.data_ptr(), wf.data_ptr(), bf.data_ptr(), mean.data_ptr(),
                                                  rstd.data_ptr(), dh.data_ptr(), dp, partial.data_ptr(), B, ctx.groups, ctx.HW,
                                                  0 if h.dtype == torch.float32 else 1, st), "pmx_gn8_gelu_backward")
-        g = partial.sum(0)
+        g = partial.sum(0).to(ctx.wdtype)
         return dh, dres, g[:, 0], g[:, 1], None, None
 
 
@@ -344,6 +345,8 @@ class MAPPOAgent(nn.Module):
         ent = -(norm.clamp(min=torch.finfo(norm.dtype).min) * probs).sum(-1)
         return self.value(merged_obs).float(), logp, ent
 
+    forward = evaluate      # torch.func.functional_call(model, params, (obs, merged, act)) == evaluate with those params
+
     @torch.no_grad()
     def act(self, obs, generator=None):
         """Sample actions for a batch: -> action [B] int64, log_prob [B] (Categorical(logits).sample, :173-177)."""
@@ -426,6 +429,43 @@ class PPOLearner:
         self.pg = process_group
         self.world_size = world_size
         self.autocast_dtype = autocast_dtype
+        self._w16 = None
+
+    def enable_bf16_flat(self):
+        """Manual mixed precision instead of autocast for the optimizer step: the network runs on ONE flat bfloat16 copy of
+        the float32 master weights (refreshed by one cast kernel per step) whose slices are the functional parameters, so
+        that autograd delivers the whole gradient as one flat bfloat16 tensor (the backward of torch.split is a single
+        concatenation).  This removes what autocast costs per step on this network: ~47 weight casts, ~46 gradient
+        casts back to float32, ~78 accumulate-into-.grad adds and the gradient memset -- about 170 of ~450 launches.  Every
+        parameter receives exactly one gradient contribution, and under autocast that contribution was computed in
+        bfloat16 as well, so storing it in bfloat16 loses nothing; master weights, Adam moments and EMA stay float32."""
+        assert self.bucket.data.is_cuda, "the flat bfloat16 path is a GPU path"
+        self._names = [n for n, p in self.model.named_parameters() if p.requires_grad]
+        self._sizes = [p.numel() for p in self.bucket.params]
+        self._shapes = [tuple(p.shape) for p in self.bucket.params]
+        self._w16 = self.bucket.data.to(torch.bfloat16).requires_grad_(True)
+        self.autocast_dtype = None
+
+    def _loss_bf16_flat(self, obs, merged, act, old_logp, adv, ret, clip_eps, ent_coef):
+        from types import SimpleNamespace
+        parts = torch.split(self._w16, self._sizes)
+        pd = {n: t.view(sh) for n, t, sh in zip(self._names, parts, self._shapes)}
+        fm = SimpleNamespace(evaluate=lambda o, m, a: torch.func.functional_call(self.model, pd, (o, m, a)))
+        return ppo_loss(fm, obs, merged, act, old_logp, adv, ret, clip_eps, ent_coef)
+
+    def _backward_into_bucket(self, loss):
+        """loss.backward() with the gradient ending up in the flat float32 bucket (zeroed / accumulated the usual way, or
+        copied from the flat bfloat16 gradient in one kernel)."""
+        if self._w16 is None:
+            loss.backward()
+            return
+        (g16,) = torch.autograd.grad(loss, (self._w16,))
+        self.bucket.grad.copy_(g16)
+
+    def _refresh_bf16(self):
+        if self._w16 is not None:
+            with torch.no_grad():
+                self._w16.copy_(self.bucket.data)
 
     def set_lr(self, lr):
         self.lr = lr
@@ -443,14 +483,17 @@ class PPOLearner:
         p.addcdiv_(self.exp_avg, denom, value=-self.lr / bc1)
 
     def update_minibatch(self, obs, merged, act, old_logp, adv, ret, clip_eps=CLIP_EPS, ent_coef=ENT_COEF_START):
-        self.bucket.grad.zero_()
         dev_type = self.bucket.data.device.type
-        if self.autocast_dtype is not None:
+        if self._w16 is not None:
+            loss, stats = self._loss_bf16_flat(obs, merged, act, old_logp, adv, ret, clip_eps, ent_coef)
+        elif self.autocast_dtype is not None:
+            self.bucket.grad.zero_()
             with torch.autocast(device_type=dev_type, dtype=self.autocast_dtype):
                 loss, stats = ppo_loss(self.model, obs, merged, act, old_logp, adv, ret, clip_eps, ent_coef)
         else:
+            self.bucket.grad.zero_()
             loss, stats = ppo_loss(self.model, obs, merged, act, old_logp, adv, ret, clip_eps, ent_coef)
-        loss.backward()
+        self._backward_into_bucket(loss)
         if self.world_size > 1:
             import torch.distributed as dist
             dist.all_reduce(self.bucket.grad, op=dist.ReduceOp.SUM, group=self.pg)
@@ -462,6 +505,7 @@ class PPOLearner:
         self.bucket.grad.mul_(torch.clamp(MAX_GRAD_NORM / (gn + 1e-6), max=1.0))
         self._adam_step()
         self.ema.mul_(EMA_DECAY).add_(self.bucket.data, alpha=1 - EMA_DECAY)
+        self._refresh_bf16()
         stats["grad_norm"] = gn.detach()
         return stats
 
@@ -492,15 +536,19 @@ class PPOLearner:
 
         def body():
             i = self._g_in
-            self.bucket.grad.zero_()
-            if self.autocast_dtype is not None:
+            if self._w16 is not None:
+                loss, stats = self._loss_bf16_flat(i["obs"], i["merged"], i["act"], i["logp"], i["adv"], i["ret"],
+                                                   self._g_sc[2], self._g_sc[3])
+            elif self.autocast_dtype is not None:
+                self.bucket.grad.zero_()
                 with torch.autocast(device_type=dev.type, dtype=self.autocast_dtype):
                     loss, stats = ppo_loss(self.model, i["obs"], i["merged"], i["act"], i["logp"], i["adv"], i["ret"],
                                            self._g_sc[2], self._g_sc[3])
             else:
+                self.bucket.grad.zero_()
                 loss, stats = ppo_loss(self.model, i["obs"], i["merged"], i["act"], i["logp"], i["adv"], i["ret"],
                                        self._g_sc[2], self._g_sc[3])
-            loss.backward()
+            self._backward_into_bucket(loss)
             if self.world_size > 1:
                 import torch.distributed as dist
                 dist.all_reduce(self.bucket.grad, op=dist.ReduceOp.SUM, group=self.pg)
@@ -515,6 +563,7 @@ class PPOLearner:
             denom = (self.exp_avg_sq.sqrt() * self._g_sc[1]).add_(self.eps)
             p.sub_(self.exp_avg / denom * self._g_sc[0])
             self.ema.mul_(EMA_DECAY).add_(p, alpha=1 - EMA_DECAY)
+            self._refresh_bf16()
             stats["grad_norm"] = gn
             return stats
 
@@ -533,6 +582,7 @@ class PPOLearner:
             self._g_stats = body()
         for t, v in zip((self.bucket.data, self.exp_avg, self.exp_avg_sq, self.ema), saved):
             t.copy_(v)
+        self._refresh_bf16()
         self._g_batch = batch
 
     def _set_graph_scalars(self, clip_eps, ent_coef, step):

@@ -55,7 +55,7 @@ def canonicalize_obs(o):
 class VecMAPPOTrainer:
     def __init__(self, layout, n_envs, horizon=32, minibatch=512, epochs=UPDATE_EPOCHS, obs_dtype="bfloat16",
                  device="cuda:0", seed=0, rank=0, world_size=1, process_group=None, total_updates=2000, length=300,
-                 use_autocast=True, opponent="random", use_graph=False, algorithm="mappo", paired_minibatches=True):
+                 use_autocast=True, opponent="random", use_graph=False, algorithm="mappo", paired_minibatches=True, flat_bf16=False):
         self.device = torch.device(device)
         self.rank, self.world_size = rank, world_size
         self.env = PmxVecEnv(layout, n_envs, length=length, reward_forLegalAction=True, defenceReward=True,
@@ -86,6 +86,10 @@ class VecMAPPOTrainer:
             import torch.distributed as dist
             dist.broadcast(self.learner.bucket.data, src=0, group=process_group)
             self.learner.ema.copy_(self.learner.bucket.data)
+        if flat_bf16:       # optimizer step on one flat bfloat16 weight copy instead of autocast (PPOLearner.enable_bf16_flat)
+            if not use_autocast:
+                raise ValueError("flat_bf16 is the bfloat16 training path; it replaces autocast in the optimizer step")
+            self.learner.enable_bf16_flat()
         self.opponent_model = mappo.MAPPOAgent(self.obs_shape, 5, 2).to(self.device)
         self.opponent_model.load_state_dict(self.model.state_dict())
         self.opponent_model.eval()
@@ -287,6 +291,7 @@ class VecMAPPOTrainer:
         self.learner.step_count, self.update_idx = ck["step"], ck["update"]
         self.opponent_pool = deque(ck["pool"], maxlen=OPPONENT_POOL_SIZE)
         self.gen.set_state(ck["gen"].cpu()); self.np_rng.set_state(ck["np_rng"])
+        self.learner._refresh_bf16()
 
 
 def evaluate_vs_bots(model, num_episodes=20, layout_file="bloxCapture", teams=("baselineTeam", "randomTeam"), length=300,

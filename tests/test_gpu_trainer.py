@@ -150,6 +150,35 @@ def test_graph_replay_bf16_stays_finite_past_230_replays():
     assert bool(torch.isfinite(L.bucket.data).all())
 
 
+def test_flat_bf16_step_tracks_autocast_step():
+    """PPOLearner.enable_bf16_flat (one flat bfloat16 weight copy, flat gradient) against the autocast step on the same data."""
+    from pmx import mappo
+    torch.manual_seed(2)
+    shape, B = (8, 11, 14), 256
+    a = mappo.MAPPOAgent(shape, 5, 2).cuda()
+    b = mappo.MAPPOAgent(shape, 5, 2).cuda()
+    b.load_state_dict(a.state_dict())
+    la = mappo.PPOLearner(a, autocast_dtype=torch.bfloat16)
+    lb = mappo.PPOLearner(b, autocast_dtype=torch.bfloat16)
+    lb.enable_bf16_flat()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for k in range(4):
+        obs = (torch.rand((B,) + shape, device="cuda", generator=g) < 0.2).to(torch.bfloat16)
+        mg = (torch.rand((B // 2,) + shape, device="cuda", generator=g) < 0.2).to(torch.bfloat16)
+        act = torch.randint(0, 5, (B,), device="cuda", generator=g)
+        logp = -1.6 + 0.05 * torch.randn(B, device="cuda", generator=g)
+        adv, ret = torch.randn(B, device="cuda", generator=g), torch.randn(B, device="cuda", generator=g)
+        sa = la.update_minibatch(obs, mg, act, logp, adv, ret)
+        sb = lb.update_minibatch(obs, mg, act, logp, adv, ret)
+        assert torch.allclose(sa["loss"], sb["loss"], rtol=3e-2, atol=3e-3), (k, sa["loss"], sb["loss"])
+        assert torch.allclose(sa["grad_norm"], sb["grad_norm"], rtol=0.15), (k, sa["grad_norm"], sb["grad_norm"])
+    # Adam moves every weight by about lr per step whatever the gradient scale, so compare the direction of the total update
+    da, db = la.bucket.data - la.ema, lb.bucket.data - lb.ema
+    cos = torch.nn.functional.cosine_similarity(da, db, dim=0)
+    assert float(cos) > 0.8, float(cos)
+    assert torch.equal(lb._w16.detach().float(), lb.bucket.data.to(torch.bfloat16).float())
+
+
 def test_unpaired_minibatches_still_run():
     """paired_minibatches=False is the reference's independent shuffle of agent samples."""
     from pmx import trainer

@@ -53,7 +53,9 @@ def run(variant):
     act = torch.randint(0, 5, (B,), device=dev)
     logp = torch.full((B,), -1.6, device=dev); adv = torch.randn(B, device=dev); ret = torch.randn(B, device=dev)
     step = learner.update_minibatch
-    if variant == "graph":
+    if variant in ("flat", "flatgraph"):
+        learner.enable_bf16_flat()
+    if variant in ("graph", "flatgraph"):
         learner.capture(B, (8, H, W), torch.bfloat16)
         step = learner.update_minibatch_graph
     for _ in range(3):
@@ -62,8 +64,10 @@ def run(variant):
     for _ in range(args.steps):
         step(obs, merged, act, logp, adv, ret)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
+    last = step(obs, merged, act, logp, adv, ret)
+    extra = {k: float(v) for k, v in last.items()}
     if args.no_infer:
-        return dict(variant=variant, batch=B, train_ms=dt * 1e3, train_samples_per_s=B / dt)
+        return dict(variant=variant, batch=B, train_ms=dt * 1e3, train_samples_per_s=B / dt, **extra)
     # inference
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         for _ in range(2):

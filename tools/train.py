@@ -26,6 +26,7 @@ ap.add_argument("--eval-every", type=int, default=0)
 ap.add_argument("--save", default="")
 ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--unpaired", action="store_true", help="the reference's independent shuffle of agent samples (critic runs per sample)")
+ap.add_argument("--flat-bf16", action="store_true", help="optimizer step on one flat bfloat16 weight copy instead of autocast")
 ap.add_argument("--graph", action="store_true", help="replay the optimizer step from a hipGraph (launch-bound minibatches, e.g. 512)")
 args = ap.parse_args()
 
@@ -40,7 +41,7 @@ from pmx import trainer
 
 tr = trainer.VecMAPPOTrainer(args.layout, args.envs, horizon=args.horizon, minibatch=args.minibatch, epochs=args.epochs,
                              obs_dtype=args.obs, device=f"cuda:{local}", seed=args.seed, rank=rank, world_size=world,
-                             total_updates=args.total_updates, opponent=args.opponent, algorithm=args.algorithm, use_graph=args.graph, paired_minibatches=not args.unpaired)
+                             total_updates=args.total_updates, opponent=args.opponent, algorithm=args.algorithm, use_graph=args.graph, paired_minibatches=not args.unpaired, flat_bf16=args.flat_bf16)
 for u in range(args.updates):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     st = tr.train_update()
