@@ -268,7 +268,8 @@ def main():
         try:
             tj = json.load(open(tpath))
             key = f"{args.workload}:{args.obs}"
-            traffic = tj.get(key, {}).get("expand_hbm_bytes_per_launch")
+            if n_envs == WORKLOADS[args.workload][1]:           # the PMC passes were taken at the workload's own env count
+                traffic = tj.get(key, {}).get("expand_hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
