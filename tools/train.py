@@ -12,7 +12,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--layout", default="smallCapture")
+ap.add_argument("--layout", default="smallCapture", help='a layout name, or "mazes": one distinct generated 20x20 maze per env (BASELINE config 5)')
+ap.add_argument("--log", default="", help="append the per-update JSON lines to this file as well (tools/plot_log.py plots it)")
 ap.add_argument("--envs", type=int, default=16384, help="envs per GPU")
 ap.add_argument("--horizon", type=int, default=32)
 ap.add_argument("--minibatch", type=int, default=8192, help="samples per optimizer step per GPU (reference: 512)")
@@ -38,8 +39,23 @@ if world > 1:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 from pmx import trainer
+import pmx
 
-tr = trainer.VecMAPPOTrainer(args.layout, args.envs, horizon=args.horizon, minibatch=args.minibatch, epochs=args.epochs,
+layout = args.layout
+if layout == "mazes":       # the reference generator's seeds, a disjoint range per rank
+    layout = [pmx.Layout.from_text(pmx.maze_generator.generate_maze(s)) for s in range(rank * args.envs + 1, (rank + 1) * args.envs + 1)]
+eval_layout = layout[:1024] if isinstance(layout, list) else layout
+
+
+def emit(rec):
+    line = json.dumps(rec)
+    print(line, flush=True)
+    if args.log:
+        with open(args.log, "a") as fh:
+            fh.write(line + "\n")
+
+
+tr = trainer.VecMAPPOTrainer(layout, args.envs, horizon=args.horizon, minibatch=args.minibatch, epochs=args.epochs,
                              obs_dtype=args.obs, device=f"cuda:{local}", seed=args.seed, rank=rank, world_size=world,
                              total_updates=args.total_updates, opponent=args.opponent, algorithm=args.algorithm, use_graph=args.graph, paired_minibatches=not args.unpaired, flat_bf16=args.flat_bf16)
 for u in range(args.updates):
@@ -48,14 +64,15 @@ for u in range(args.updates):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     if rank == 0:
         f = lambda k: float(st[k]) if k in st else None
-        print(json.dumps(dict(update=u, opponent=st["opponent"], red=st["play_as_red"], sec=round(dt, 3),
+        emit(dict(update=u, algorithm=args.algorithm, opponent=st["opponent"], red=st["play_as_red"], sec=round(dt, 3),
                               env_steps_per_s=round(world * tr.N * tr.T / dt), episodes=int(st["episodes"]),
                               win_rate=(float(st["wins"]) / max(int(st["episodes"]), 1)),
                               reward=float(st["rollout_reward"]) / max(tr.N, 1), pg=f("pg"), vl=f("vl"), entropy=f("entropy"),
-                              clip_frac=f("clip_frac"), grad_norm=f("grad_norm"), steps=st["optimizer_steps"])), flush=True)
+                              clip_frac=f("clip_frac"), grad_norm=f("grad_norm"), steps=st["optimizer_steps"]))
         if args.eval_every and u and u % args.eval_every == 0:
-            print(json.dumps(dict(update=u, eval_vs_baseline=trainer.evaluate_vectorized(tr.model, args.layout, 1024, "baseline", device=f"cuda:{local}"),
-                                  eval_vs_random=trainer.evaluate_vectorized(tr.model, args.layout, 1024, "random", device=f"cuda:{local}"))), flush=True)
+            emit(dict(update=u, algorithm=args.algorithm,
+                      eval_vs_baseline=trainer.evaluate_vectorized(tr.model, eval_layout, 1024, "baseline", device=f"cuda:{local}"),
+                      eval_vs_random=trainer.evaluate_vectorized(tr.model, eval_layout, 1024, "random", device=f"cuda:{local}")))
 if rank == 0 and args.save:
     tr.save_ema(args.save)
 if world > 1:
