@@ -11,7 +11,7 @@ collective); the timed region is bracketed by barrier + synchronize and the repo
 
 The JSON line also carries
   roofline      the observation-expansion kernel (>95 % of the bytes): algorithmic bytes per launch / its average
-                duration measured with HIP events on the launch stream (pmx_profile_begin/end) vs the 8 TB/s HBM peak
+                duration from start/stop HIP events attached to each dispatch on the launch stream (pmx_profile_begin/end) vs the 8 TB/s HBM peak
   cpu_baseline  the CPU oracle (a port of the reference's tick, oracle/pmx_oracle.c) on one host core, bounded sample
 """
 import argparse
@@ -240,7 +240,7 @@ def main():
         dt = float(tmax.item())
     checksum = int(env.obs.sum(dtype=torch.float64).item()) if args.obs != "uint8" else int(env.obs.sum().item())
 
-    # second pass, same K steps, with HIP events around each kernel launch: per-kernel durations for the roofline
+    # second pass, same K steps, with start/stop HIP events attached to each kernel dispatch: per-kernel durations for the roofline
     env.profile_begin(args.steps + 8)
     for k in range(args.steps):
         env.step(actions[k % n_act])

@@ -171,9 +171,10 @@ int pmx_maze_distances(pmx_env *env, int8_t *cells_dev, uint8_t *dist_dev, int32
 /* the same for layout `layout` of a multi-layout handle */
 int pmx_maze_distances_layout(pmx_env *env, int32_t layout, int8_t *cells_dev, uint8_t *dist_dev, int32_t *n_cells, void *stream);
 
-/* Measurement hooks (no reference counterpart): between begin and end, every tick records a HIP event pair around
- * its rule-kernel and its expansion-kernel launch on the caller's stream; end synchronises them and returns the
- * summed kernel durations (milliseconds) and launch counts.  bench.py's roofline figures come from here. */
+/* Measurement hooks (no reference counterpart): between begin and end, every tick attaches a start and a stop HIP event
+ * to its rule-kernel and to its expansion-kernel dispatch on the caller's stream (hipExtLaunchKernelGGL); end
+ * synchronises them and returns the summed kernel durations (milliseconds) and launch counts.  bench.py's roofline
+ * figures come from here. */
 int pmx_profile_begin(pmx_env *env, int32_t max_launches);
 int pmx_profile_end(pmx_env *env, double *rule_ms, int32_t *rule_launches, double *expand_ms, int32_t *expand_launches);
 

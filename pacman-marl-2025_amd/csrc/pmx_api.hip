@@ -9,11 +9,11 @@
 #include "../../include/pmx.h"
 #include "pmx_device.h"
 
-extern "C" hipError_t pmx_launch_rule(const PmxTickParams *p, int H, hipStream_t st);
+extern "C" hipError_t pmx_launch_rule(const PmxTickParams *p, int H, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 extern "C" hipError_t pmx_launch_rule_agent(const PmxTickParams *p, int H, int agent, hipStream_t st);
 extern "C" hipError_t pmx_launch_reset(const PmxTickParams *p, int H, hipStream_t st);
 extern "C" hipError_t pmx_launch_successor(const PmxTickParams *p, int H, int agent, hipStream_t st);
-extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, int dtype, hipStream_t st);
+extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, int dtype, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 extern "C" hipError_t pmx_launch_maze(const PmxLayoutDev *lay_dev, const int16_t *cell_index_dev, int n_cells,
                                       const int8_t *cells_dev, uint8_t *dist_dev, hipStream_t st);
 
@@ -154,10 +154,8 @@ int launch_expand(pmx_env *env, void *obs, bool from_snapshots, int single_agent
         x.n_emit = env->n_emit;
         for (int i = 0; i < 4; ++i) x.emit[i] = env->emit[i];
     }
-    hipEvent_t *ev = prof_pair(env, true);
-    if (ev) HIP_TRY(hipEventRecord(ev[0], st));
-    HIP_TRY(pmx_launch_expand(&x, env->cfg.obs_dtype, st));
-    if (ev) HIP_TRY(hipEventRecord(ev[1], st));
+    hipEvent_t *ev = prof_pair(env, true);       // profiling: the dispatch's own start / stop timestamps
+    HIP_TRY(pmx_launch_expand(&x, env->cfg.obs_dtype, st, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr));
     return PMX_OK;
 }
 
@@ -373,9 +371,7 @@ int pmx_step(pmx_env *env, const int8_t *actions_dev, const pmx_step_out *out, v
     PmxTickParams p;
     fill_tick_params(env, p, actions_dev, out);
     hipEvent_t *ev = prof_pair(env, false);
-    if (ev) HIP_TRY(hipEventRecord(ev[0], as_stream(stream)));
-    HIP_TRY(pmx_launch_rule(&p, env->lay.H, as_stream(stream)));
-    if (ev) HIP_TRY(hipEventRecord(ev[1], as_stream(stream)));
+    HIP_TRY(pmx_launch_rule(&p, env->lay.H, as_stream(stream), ev ? ev[0] : nullptr, ev ? ev[1] : nullptr));
     if (out && out->obs_dev) return launch_expand(env, out->obs_dev, true, -1, as_stream(stream));
     return PMX_OK;
 }

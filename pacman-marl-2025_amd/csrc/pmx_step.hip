@@ -12,6 +12,8 @@
 // N*4 wavefronts of perfectly coalesced stores regardless of N.
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 #include "pmx_device.h"
 
 #define PMX_MAX_H_LDS 32   // per-lane wall columns (multi-layout handles) start after room for 32 food rows
@@ -779,13 +781,19 @@ __global__ __launch_bounds__(PMX_BLOCK) void pmx_expand_kernel(PmxExpandParams p
 // ---------------------------------------------------------------------------------------------------------------
 // host-side launchers (called by the C ABI in pmx_api.hip)
 // ---------------------------------------------------------------------------------------------------------------
-extern "C" hipError_t pmx_launch_rule(const PmxTickParams *p, int H, hipStream_t st)
+// ev0/ev1 (both or neither): events that receive the START and STOP timestamps of this very dispatch (hipExtLaunchKernelGGL),
+// i.e. the kernel's own duration as a profiler sees it, without the dispatch gaps a hipEventRecord pair would include
+extern "C" hipError_t pmx_launch_rule(const PmxTickParams *p, int H, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1)
 {
     const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
     const size_t lds = (p->layout_idx ? 32 + (size_t)(2 * PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)2 * H * PMX_RULE_BLOCK) * sizeof(uint32_t);
     // row loops unrolled for the board-height bucket (see load_env_issue)
     const int hb = H <= 12 ? 12 : (H <= 16 ? 16 : (H <= 20 ? 20 : 32));
-#define PMX_RULE_LAUNCH(B, HBV) hipLaunchKernelGGL((pmx_rule_kernel<B, HBV>), dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p)
+#define PMX_RULE_LAUNCH(B, HBV)                                                                                         \
+    do {                                                                                                                \
+        if (ev0) hipExtLaunchKernelGGL((pmx_rule_kernel<B, HBV>), dim3(blocks), dim3(PMX_RULE_BLOCK), (uint32_t)lds, st, ev0, ev1, 0, *p); \
+        else hipLaunchKernelGGL((pmx_rule_kernel<B, HBV>), dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p);              \
+    } while (0)
 #define PMX_RULE_PICK(B)                                                                      \
     switch (hb) {                                                                             \
     case 12: PMX_RULE_LAUNCH(B, 12); break;                                                   \
@@ -822,7 +830,7 @@ extern "C" hipError_t pmx_launch_reset(const PmxTickParams *p, int H, hipStream_
     return hipGetLastError();
 }
 
-extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, int dtype, hipStream_t st)
+extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, int dtype, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1)
 {
     const long waves = (long)p->N * p->n_emit;
     const unsigned blocks = (unsigned)((waves + 3) / 4);
@@ -845,10 +853,14 @@ extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, int dtype, hip
     if (const char *o = getenv("PMX_EXPAND_NT")) nt = atoi(o) != 0;      // experiment override
     size_t lds_pad = (nt && elem == 4) ? 40000 : 0;
     if (const char *o = getenv("PMX_EXPAND_LDS_PAD")) lds_pad = (size_t)atoi(o);   // experiment override
-#define PMX_EXPAND_LAUNCH(DT)                                                                              \
-    do {                                                                                                   \
-        if (nt) hipLaunchKernelGGL((pmx_expand_kernel<DT, true>), dim3(blocks), dim3(PMX_BLOCK), lds_pad, st, *p); \
-        else hipLaunchKernelGGL((pmx_expand_kernel<DT, false>), dim3(blocks), dim3(PMX_BLOCK), lds_pad, st, *p);   \
+#define PMX_EXPAND_LAUNCH1(DT, NTV)                                                                                     \
+    do {                                                                                                                \
+        if (ev0) hipExtLaunchKernelGGL((pmx_expand_kernel<DT, NTV>), dim3(blocks), dim3(PMX_BLOCK), (uint32_t)lds_pad, st, ev0, ev1, 0, *p); \
+        else hipLaunchKernelGGL((pmx_expand_kernel<DT, NTV>), dim3(blocks), dim3(PMX_BLOCK), lds_pad, st, *p);            \
+    } while (0)
+#define PMX_EXPAND_LAUNCH(DT)                                                                                           \
+    do {                                                                                                                \
+        if (nt) PMX_EXPAND_LAUNCH1(DT, true); else PMX_EXPAND_LAUNCH1(DT, false);                                       \
     } while (0)
     switch (dtype) {
     case 0: PMX_EXPAND_LAUNCH(0); break;
