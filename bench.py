@@ -245,6 +245,17 @@ def main():
     for k in range(args.steps):
         env.step(actions[k % n_act])
     prof = env.profile_end()
+    # third, short pass with the alternating sweep switched off (PMX_EXPAND_ALT is read at every launch): what the expansion
+    # kernel does when every byte has to go to HBM, i.e. without tick t+1 overwriting the tail of tick t in the Infinity Cache
+    k_uni = min(args.steps, 300)
+    os.environ["PMX_EXPAND_ALT"] = "0"
+    for k in range(20):
+        env.step(actions[k % n_act])
+    env.profile_begin(k_uni + 8)
+    for k in range(k_uni):
+        env.step(actions[k % n_act])
+    prof_uni = env.profile_end()
+    del os.environ["PMX_EXPAND_ALT"]
     e = ELEM[args.obs]
     expand_bytes = n_envs * 4 * 8 * H * W * e                      # algorithmic bytes of one expansion launch
     expand_s = prof["expand_ms"] / 1e3 / max(prof["expand_launches"], 1)
@@ -290,9 +301,16 @@ def main():
             "tick_GBps": value / world * B / 1e9,
             "roofline": {"bound": "hbm", "kernel": "pmx_expand_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_scope": "PMC TCC FETCH_SIZE/WRITE_SIZE = L2 <-> fabric requests; the Infinity Cache sits behind them",
                          "algorithmic_bytes_per_launch": expand_bytes, "avg_launch_us": expand_s * 1e6,
                          "launches": prof["expand_launches"], "rule_kernel_avg_us": rule_s * 1e6,
-                         "same_device_fill_GBps": write_ceiling},
+                         "same_device_fill_GBps": write_ceiling,
+                         "unidirectional_sweep": {
+                             "avg_launch_us": prof_uni["expand_ms"] * 1e3 / max(prof_uni["expand_launches"], 1),
+                             "achieved": expand_bytes / (prof_uni["expand_ms"] / 1e3 / max(prof_uni["expand_launches"], 1)) / 1e9,
+                             "note": "same kernel with PMX_EXPAND_ALT=0: every tick walks the planes in the same direction, so all "
+                                     "bytes reach HBM; the default alternates the direction and tick t+1 overwrites the tail of tick t "
+                                     "while it is still in the 256 MiB Infinity Cache (those lines never cost an HBM write)"}},
             "obs_checksum": checksum,
         }
         if not args.no_cpu_baseline and world == 1:

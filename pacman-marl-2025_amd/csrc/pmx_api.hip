@@ -41,6 +41,7 @@ struct pmx_env {
     int open_agent;            // next agent expected by pmx_step_agent
     // optional per-kernel timing (pmx_profile_begin/end): pairs of events around each launch
     bool profiling;
+    uint64_t expand_launches = 0;   // parity selects the direction of the expansion sweep
     std::vector<hipEvent_t> ev_rule, ev_expand;
     size_t ev_rule_used, ev_expand_used;
 };
@@ -153,6 +154,12 @@ int launch_expand(pmx_env *env, void *obs, bool from_snapshots, int single_agent
     } else {
         x.n_emit = env->n_emit;
         for (int i = 0; i < 4; ++i) x.emit[i] = env->emit[i];
+    }
+    if (single_agent < 0) {
+        // alternate the direction of the sweep over the planes from tick to tick (see pmx_launch_expand); PMX_EXPAND_ALT=0
+        // switches it off for A/B measurements
+        const char *o = getenv("PMX_EXPAND_ALT");
+        if (!o || atoi(o) != 0) x.reverse = (int32_t)(env->expand_launches++ & 1);
     }
     hipEvent_t *ev = prof_pair(env, true);       // profiling: the dispatch's own start / stop timestamps
     HIP_TRY(pmx_launch_expand(&x, env->cfg.obs_dtype, st, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr));

@@ -82,4 +82,5 @@ struct PmxExpandParams {
     int32_t emit[4];             // agent index of each emitted slot
     int32_t single_agent;        // >= 0: obs is [N][8][H][W] for that agent only (pmx_step_agent)
     int32_t lay_H, lay_W;        // host-side copies of the common layout dimensions (launch sizing)
+    int32_t reverse;             // 1: walk the blocks from the highest address down (alternate ticks, see pmx_launch_expand)
 };

@@ -707,7 +707,7 @@ __global__ __launch_bounds__(PMX_BLOCK) void pmx_expand_kernel(PmxExpandParams p
     const int W = p.lay->W, H = p.lay->H;
     const int HW = H * W;
     const long total = (long)p.N * p.n_emit;
-    long blk = blockIdx.x;
+    long blk = p.reverse ? (long)gridDim.x - 1 - (long)blockIdx.x : (long)blockIdx.x;
     if (p.n_emit == 4 && (p.N & 127) == 0) {
         // XCD-aware order: blocks b, b+8, b+16, .. share an XCD and its L2.  Give each XCD 16 consecutive envs, i.e. the
         // envs whose SoA snapshot words share 64-byte lines, so that a line is fetched into one L2 instead of eight
@@ -845,14 +845,23 @@ extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, int dtype, hip
     // write stream, and 12 waves per CU instead of 32 keep the number of DRAM pages open at once low enough for the
     // write-combined bursts to stay row-buffer hits (6.2 TB/s instead of 5.3 at 1.29 GB).  The occupancy cap is an
     // unused dynamic-LDS reservation of 40 000 bytes per block (3 blocks of 4 waves fit the 160 KB of a CU).
+    // (the cap is for float32 only: the bf16 / uint8 variants are issue-bound and lose up to 2x with it)
+    //
+    // Alternating sweep: a caller steps the same observation buffer tick after tick, and the last part written in tick t is
+    // still in the Infinity Cache when tick t+1 starts.  Walking the blocks in the opposite direction every other tick makes
+    // tick t+1 overwrite exactly those lines first, while they are still cached, so they never cost an HBM write:
+    //   f32 small 323 MB  51.4 -> 43.8 us      blox 419 MB  75.7 -> 60.4      blox 839 MB  151.8 -> 125.1
+    //       small 646 MB 118.7 -> 108.6 (streaming + cap: 105-107)       small 1.29 GB  271 -> 257 (streaming + cap: 208)
+    // It needs ordinary (cache-allocating) stores, so float32 planes up to 900 MB now use them; p->reverse carries the parity.
     const size_t elem = dtype == 0 ? 4 : (dtype == 1 ? 2 : 1);
     const size_t bytes = (size_t)waves * 8 * p->lay_H * p->lay_W * elem;
-    // (the cap is for float32 only: the bf16 / uint8 variants are issue-bound and lose up to 2x with it; on 20x20 boards,
-    // 51 KB per wave, all four combinations are within 6 % of each other and nt + cap is never the worst)
-    bool nt = elem == 1 || bytes > ((size_t)480 << 20);
+    bool nt = elem == 1 || (elem == 2 && bytes > ((size_t)512 << 20)) || (elem == 4 && bytes > ((size_t)900 << 20));
     if (const char *o = getenv("PMX_EXPAND_NT")) nt = atoi(o) != 0;      // experiment override
     size_t lds_pad = (nt && elem == 4) ? 40000 : 0;
     if (const char *o = getenv("PMX_EXPAND_LDS_PAD")) lds_pad = (size_t)atoi(o);   // experiment override
+    PmxExpandParams q = *p;
+    if (nt) q.reverse = 0;
+    p = &q;
 #define PMX_EXPAND_LAUNCH1(DT, NTV)                                                                                     \
     do {                                                                                                                \
         if (ev0) hipExtLaunchKernelGGL((pmx_expand_kernel<DT, NTV>), dim3(blocks), dim3(PMX_BLOCK), (uint32_t)lds_pad, st, ev0, ev1, 0, *p); \
