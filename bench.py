@@ -179,6 +179,7 @@ def main():
     ap.add_argument("--envs", type=int, default=0, help="override envs per GPU")
     ap.add_argument("--obs", default="float32", choices=sorted(ELEM))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-unidirectional", action="store_true", help="skip the short comparison pass with PMX_EXPAND_ALT=0 (for profiler runs)")
     ap.add_argument("--no-ppo", action="store_true", help="skip the short MAPPO rollout/update probe")
     args = ap.parse_args()
 
@@ -247,15 +248,17 @@ def main():
     prof = env.profile_end()
     # third, short pass with the alternating sweep switched off (PMX_EXPAND_ALT is read at every launch): what the expansion
     # kernel does when every byte has to go to HBM, i.e. without tick t+1 overwriting the tail of tick t in the Infinity Cache
-    k_uni = min(args.steps, 300)
-    os.environ["PMX_EXPAND_ALT"] = "0"
-    for k in range(20):
-        env.step(actions[k % n_act])
-    env.profile_begin(k_uni + 8)
-    for k in range(k_uni):
-        env.step(actions[k % n_act])
-    prof_uni = env.profile_end()
-    del os.environ["PMX_EXPAND_ALT"]
+    prof_uni = None
+    if not args.no_unidirectional:
+        k_uni = min(args.steps, 300)
+        os.environ["PMX_EXPAND_ALT"] = "0"
+        for k in range(20):
+            env.step(actions[k % n_act])
+        env.profile_begin(k_uni + 8)
+        for k in range(k_uni):
+            env.step(actions[k % n_act])
+        prof_uni = env.profile_end()
+        del os.environ["PMX_EXPAND_ALT"]
     e = ELEM[args.obs]
     expand_bytes = n_envs * 4 * 8 * H * W * e                      # algorithmic bytes of one expansion launch
     expand_s = prof["expand_ms"] / 1e3 / max(prof["expand_launches"], 1)
@@ -305,7 +308,7 @@ def main():
                          "algorithmic_bytes_per_launch": expand_bytes, "avg_launch_us": expand_s * 1e6,
                          "launches": prof["expand_launches"], "rule_kernel_avg_us": rule_s * 1e6,
                          "same_device_fill_GBps": write_ceiling,
-                         "unidirectional_sweep": {
+                         "unidirectional_sweep": None if prof_uni is None else {
                              "avg_launch_us": prof_uni["expand_ms"] * 1e3 / max(prof_uni["expand_launches"], 1),
                              "achieved": expand_bytes / (prof_uni["expand_ms"] / 1e3 / max(prof_uni["expand_launches"], 1)) / 1e9,
                              "note": "same kernel with PMX_EXPAND_ALT=0: every tick walks the planes in the same direction, so all "

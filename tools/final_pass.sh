@@ -11,7 +11,7 @@ timeout -k 10 300 python bench.py --obs uint8 --no-ppo > gpurun_out/final/bench_
 timeout -k 10 300 python bench.py --envs 65536 --no-ppo > gpurun_out/final/bench_small65536.json 2>/dev/null
 timeout -k 10 300 python bench.py --workload blox4096 --envs 16384 --no-ppo > gpurun_out/final/bench_blox16384.json 2>/dev/null
 cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_final -o fin -- python3 $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 50 --no-cpu-baseline --no-ppo > /tmp/prof_final.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_final -o fin -- python3 $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 50 --no-cpu-baseline --no-ppo --no-unidirectional > /tmp/prof_final.log 2>&1
 cd $GRAFT_REPO_ROOT
 cp $(find /tmp/prof_final -name "*kernel_stats.csv" | head -1) gpurun_out/final/kernel_stats_small16384_f32.csv
 bash tools/pmc_pass.sh small16384 float32 fin > gpurun_out/final/pmc.log 2>&1 || echo "pmc pass failed"
