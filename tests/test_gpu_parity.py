@@ -506,3 +506,42 @@ def test_in_kernel_baseline_bots_vs_oracle(layname):
         score_seen.update(orc.score.tolist())
     assert len(score_seen) >= 2                        # the bots do eat and return food (the reference scores 11 at once on tiny)
     env.close()
+
+
+@pytest.mark.parametrize("layname", ["smallCapture", "bloxCapture"])
+def test_soak_four_episodes_mixed_controllers_vs_oracle(layname):
+    """A long run (4 full episodes with auto-reset, 1 210 ticks) in which every env mixes the three kinds of controllers that
+    produce the rare rule paths -- reflex bots that chase, kill and carry food home, random-legal wanderers and raw (also
+    illegal / out-of-range) action codes -- compared with the oracle on every output of every tick (state compared at the end)."""
+    pmx = _pmx()
+    lay = pmx.get_layout(layname)
+    N, T = 192, 1210
+    env = pmx.PmxVecEnv(lay, N, length=300, auto_reset=True, seed=77, bots=True, obs_dtype="uint8")
+    orc = O.BatchEnv(lay.text, N, length=300, auto_reset=True, seed=77)
+    O.set_bot_tables(O.bot_tables(lay.text))
+    env.reset()
+    rng = np.random.RandomState(123)
+    kind = rng.randint(0, 4, size=(N, 4))              # per (env, agent): 0 offensive bot, 1 defensive bot, 2 random-legal, 3 raw codes
+    oobs = np.zeros((N, 4, 8, lay.height, lay.width), np.float32)
+    n_done = 0
+    deaths = 0
+    prev_carry = np.zeros((N, 4), np.int64)
+    for t in range(T):
+        raw = rng.randint(-1, 7, size=(N, 4)).astype(np.int8)
+        a = np.where(kind == 0, -3, np.where(kind == 1, -4, np.where(kind == 2, -2, raw))).astype(np.int8)
+        orc.tick(a, oobs)
+        obs, rew, done, info = env.step(torch.tensor(a).cuda())
+        assert rew.cpu().numpy().tobytes() == orc.reward.tobytes(), t
+        assert (done.cpu().numpy() == orc.done).all(), t
+        assert (info["legal_actions"].cpu().numpy() == orc.legal).all(), t
+        assert (info["agent"].cpu().numpy().astype(np.uint32) == orc.agent).all(), t
+        assert (info["score"].cpu().numpy() == orc.score).all() and (info["score_change"].cpu().numpy() == orc.score_change).all(), t
+        if t % 7 == 0 or orc.done.any():
+            assert (obs.cpu().numpy() == oobs.astype(np.uint8)).all(), t
+        carry = (orc.agent >> 16).astype(np.int64)
+        deaths += int(((prev_carry >= 2) & (carry == 0) & (orc.score_change[:, None] == 0)).sum())
+        prev_carry = carry
+        n_done += int(orc.done.sum())
+    assert n_done >= 4 * N                              # at least the four time-outs; the bots also end games early by winning
+    assert deaths > 0                                   # carriers did lose their food (kills with dumps happened)
+    env.close()
