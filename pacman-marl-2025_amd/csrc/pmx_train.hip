@@ -598,9 +598,12 @@ __global__ __launch_bounds__(512) void pmx_attn8_fwd_kernel(const __hip_bfloat16
         const int q_row = qt * 16 + c;
         pmx_bf16x8 qf = zero8;
         if (g == 0 && q_row < S) qf = *reinterpret_cast<const pmx_bf16x8 *>(base + (size_t)q_row * row_stride + head_off);
+        // Scores stay in the raw (unscaled) domain; c2 = scale * log2(e) turns them into base-2 exponents with ONE fma per
+        // element (exp2(s * c2 - m)), the running maximum m and the stored log-sum-exp are kept in that base-2 domain.
         float m = -1e30f, l = 0.f;
         pmx_f32x4 o = { 0.f, 0.f, 0.f, 0.f };
-        for (int kp = 0; kp < n_kp; ++kp) {
+        const float c2 = scale * 1.44269504088896341f;
+        auto tile = [&](int kp, bool last) {
             pmx_bf16x8 k0 = zero8, k1 = zero8;
             if (g == 0) {
                 k0 = *reinterpret_cast<const pmx_bf16x8 *>(Ks + (size_t)(kp * 32 + c) * D);
@@ -610,23 +613,26 @@ __global__ __launch_bounds__(512) void pmx_attn8_fwd_kernel(const __hip_bfloat16
             pmx_f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf, z4, 0, 0, 0);
             pmx_f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf, z4, 0, 0, 0);
             float p[8];
-            float mloc = -1e30f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key0 = kp * 32 + g * 4 + r, key1 = key0 + 16;
-                p[r] = key0 < S ? s0[r] * scale : -1e30f;
-                p[4 + r] = key1 < S ? s1[r] * scale : -1e30f;
-                mloc = fmaxf(mloc, fmaxf(p[r], p[4 + r]));
+            for (int r = 0; r < 4; ++r) { p[r] = s0[r]; p[4 + r] = s1[r]; }
+            if (last) {   // only the last key pair can hold padded keys: they must not enter the row sum
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key0 = kp * 32 + g * 4 + r, key1 = key0 + 16;
+                    if (key0 >= S) p[r] = -1e30f;
+                    if (key1 >= S) p[4 + r] = -1e30f;
+                }
             }
+            float mloc = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
             mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-            const float mnew = fmaxf(m, mloc);
-            const float alpha = __expf(m - mnew);
+            const float mnew = fmaxf(m, mloc * c2);
+            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
             float lsum = 0.f;
             pmx_bf16x8 pf;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const float e = __expf(p[r] - mnew);
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(p[r], c2, -mnew));
                 lsum += e;
                 pf[r] = pmx_f2bf(e);
             }
@@ -646,7 +652,9 @@ __global__ __launch_bounds__(512) void pmx_attn8_fwd_kernel(const __hip_bfloat16
                 vf = *reinterpret_cast<const pmx_bf16x8 *>(&both);
             }
             o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o, 0, 0, 0);
-        }
+        };
+        for (int kp = 0; kp < n_kp - 1; ++kp) tile(kp, false);
+        tile(n_kp - 1, true);
         // O^T[d = 4g + r][query c]: lanes of groups 0 and 1 hold d = 0..3 and 4..7
         if (q_row < S) {
             const float inv = 1.0f / l;
@@ -657,7 +665,7 @@ __global__ __launch_bounds__(512) void pmx_attn8_fwd_kernel(const __hip_bfloat16
                 *reinterpret_cast<uint2 *>(reinterpret_cast<short *>(out) + ((size_t)q_row * B + b) * E + h * D + g * 4) =
                     *reinterpret_cast<const uint2 *>(w4);
             }
-            if (g == 0 && lse) lse[((size_t)b * HEADS + h) * S + q_row] = m + __logf(l);
+            if (g == 0 && lse) lse[((size_t)b * HEADS + h) * S + q_row] = (m + __log2f(l)) * 0.69314718055994531f;   // back to the natural log
         }
     }
 }
@@ -724,7 +732,7 @@ __global__ __launch_bounds__(512) void pmx_attn8_bwd_kernel(const __hip_bfloat16
             kv = *reinterpret_cast<const uint4 *>(base + (size_t)s * row_stride + head_off + E);
             dov = *reinterpret_cast<const uint4 *>(dobase + (size_t)s * orow + ohead);
             ov = *reinterpret_cast<const uint4 *>(obase + (size_t)s * orow + ohead);
-            ls = lse[((size_t)b * HEADS + h) * S + s];
+            ls = lse[((size_t)b * HEADS + h) * S + s] * 1.44269504088896341f;      // natural log -> the base-2 domain of exp2 below
         }
         const short *q8 = reinterpret_cast<const short *>(&qv), *k8 = reinterpret_cast<const short *>(&kv);
         const short *d8 = reinterpret_cast<const short *>(&dov), *o8 = reinterpret_cast<const short *>(&ov);
@@ -744,6 +752,7 @@ __global__ __launch_bounds__(512) void pmx_attn8_bwd_kernel(const __hip_bfloat16
     const pmx_bf16x8 zero8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
     const pmx_f32x4 z4 = { 0.f, 0.f, 0.f, 0.f };
     const int n_t = (S + 15) >> 4, n_p = S_pad >> 5;
+    const float c2 = scale * 1.44269504088896341f;     // scores -> base-2 exponents with one fma: exp2(s * c2 - lse2)
     short *dbase = reinterpret_cast<short *>(dqkv);
 
     auto row8 = [&](const short *src, size_t stride, size_t off, int r) -> pmx_bf16x8 {   // 8 bf16 of row r for lanes of group 0
@@ -768,21 +777,29 @@ __global__ __launch_bounds__(512) void pmx_attn8_bwd_kernel(const __hip_bfloat16
         const int q_row = qt * 16 + c;
         const pmx_bf16x8 qf = row8(base, row_stride, head_off, q_row);
         const pmx_bf16x8 dof = row8(dobase, orow, ohead, q_row);
-        const float ls = lse_s[q_row < S_pad ? q_row : 0], dl = delta_s[q_row < S_pad ? q_row : 0];
+        // (the clamp only matters for the zero K rows of padded keys: exp2(-ls) must stay finite so that 0 * dS is 0 in the MFMA)
+        const float ls = fmaxf(lse_s[q_row < S_pad ? q_row : 0], -120.f), dl = delta_s[q_row < S_pad ? q_row : 0];
         pmx_f32x4 dq = z4;
+        // software pipeline: the row fragments of key pair kp + 1 are requested before pair kp is consumed (the loads are
+        // L2 hits several hundred cycles away and the compiler does not hoist them across the loop by itself)
+        pmx_bf16x8 k0n = row8(base, row_stride, head_off + E, c), k1n = row8(base, row_stride, head_off + E, 16 + c);
+        pmx_bf16x8 v0n = row8(base, row_stride, head_off + 2 * E, c), v1n = row8(base, row_stride, head_off + 2 * E, 16 + c);
         for (int kp = 0; kp < n_p; ++kp) {
-            const pmx_bf16x8 k0 = row8(base, row_stride, head_off + E, kp * 32 + c), k1 = row8(base, row_stride, head_off + E, kp * 32 + 16 + c);
-            const pmx_bf16x8 v0 = row8(base, row_stride, head_off + 2 * E, kp * 32 + c), v1 = row8(base, row_stride, head_off + 2 * E, kp * 32 + 16 + c);
+            const pmx_bf16x8 k0 = k0n, k1 = k1n, v0 = v0n, v1 = v1n;
+            if (kp + 1 < n_p) {
+                k0n = row8(base, row_stride, head_off + E, kp * 32 + 32 + c); k1n = row8(base, row_stride, head_off + E, kp * 32 + 48 + c);
+                v0n = row8(base, row_stride, head_off + 2 * E, kp * 32 + 32 + c); v1n = row8(base, row_stride, head_off + 2 * E, kp * 32 + 48 + c);
+            }
             const pmx_f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf, z4, 0, 0, 0);
             const pmx_f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf, z4, 0, 0, 0);
             const pmx_f32x4 p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, dof, z4, 0, 0, 0);
             const pmx_f32x4 p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, dof, z4, 0, 0, 0);
+            // no key mask: the K^T columns of padded keys are zero in LDS, so whatever dS holds there contributes nothing
             pmx_bf16x8 dsf;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key0 = kp * 32 + g * 4 + r, key1 = key0 + 16;
-                const float e0 = key0 < S ? __expf(s0[r] * scale - ls) : 0.f;
-                const float e1 = key1 < S ? __expf(s1[r] * scale - ls) : 0.f;
+                const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c2, -ls));
+                const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c2, -ls));
                 dsf[r] = pmx_f2bf(e0 * (p0[r] - dl));
                 dsf[4 + r] = pmx_f2bf(e1 * (p1[r] - dl));
             }
@@ -802,9 +819,14 @@ __global__ __launch_bounds__(512) void pmx_attn8_bwd_kernel(const __hip_bfloat16
         const pmx_bf16x8 kf = row8(base, row_stride, head_off + E, k_row);
         const pmx_bf16x8 vf = row8(base, row_stride, head_off + 2 * E, k_row);
         pmx_f32x4 dk = z4, dv = z4;
+        pmx_bf16x8 q0n = row8(base, row_stride, head_off, c), q1n = row8(base, row_stride, head_off, 16 + c);
+        pmx_bf16x8 d0n = row8(dobase, orow, ohead, c), d1n = row8(dobase, orow, ohead, 16 + c);
         for (int qp = 0; qp < n_p; ++qp) {
-            const pmx_bf16x8 q0 = row8(base, row_stride, head_off, qp * 32 + c), q1 = row8(base, row_stride, head_off, qp * 32 + 16 + c);
-            const pmx_bf16x8 d0 = row8(dobase, orow, ohead, qp * 32 + c), d1 = row8(dobase, orow, ohead, qp * 32 + 16 + c);
+            const pmx_bf16x8 q0 = q0n, q1 = q1n, d0 = d0n, d1 = d1n;
+            if (qp + 1 < n_p) {
+                q0n = row8(base, row_stride, head_off, qp * 32 + 32 + c); q1n = row8(base, row_stride, head_off, qp * 32 + 48 + c);
+                d0n = row8(dobase, orow, ohead, qp * 32 + 32 + c); d1n = row8(dobase, orow, ohead, qp * 32 + 48 + c);
+            }
             // S = Q . K^T: rows = queries (4g + r), column = key c
             const pmx_f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, kf, z4, 0, 0, 0);
             const pmx_f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, kf, z4, 0, 0, 0);
@@ -814,8 +836,9 @@ __global__ __launch_bounds__(512) void pmx_attn8_bwd_kernel(const __hip_bfloat16
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qa = qp * 32 + g * 4 + r, qb = qa + 16;
-                const float e0 = k_row < S ? __expf(s0[r] * scale - lse_s[qa]) : 0.f;      // padded queries carry lse = 1e30
-                const float e1 = k_row < S ? __expf(s1[r] * scale - lse_s[qb]) : 0.f;
+                // padded queries carry lse = 1e30 (probability 0); a padded KEY is this lane's own column, which is never stored
+                const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c2, -lse_s[qa]));
+                const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c2, -lse_s[qb]));
                 pf[r] = pmx_f2bf(e0); pf[4 + r] = pmx_f2bf(e1);
                 dsf[r] = pmx_f2bf(e0 * (p0[r] - delta_s[qa]));
                 dsf[4 + r] = pmx_f2bf(e1 * (p1[r] - delta_s[qb]));
