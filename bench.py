@@ -251,6 +251,7 @@ def main():
     prof_uni = None
     if not args.no_unidirectional:
         k_uni = min(args.steps, 300)
+        prev_alt = os.environ.get("PMX_EXPAND_ALT")
         os.environ["PMX_EXPAND_ALT"] = "0"
         for k in range(20):
             env.step(actions[k % n_act])
@@ -258,7 +259,10 @@ def main():
         for k in range(k_uni):
             env.step(actions[k % n_act])
         prof_uni = env.profile_end()
-        del os.environ["PMX_EXPAND_ALT"]
+        if prev_alt is None:
+            del os.environ["PMX_EXPAND_ALT"]
+        else:
+            os.environ["PMX_EXPAND_ALT"] = prev_alt
     e = ELEM[args.obs]
     expand_bytes = n_envs * 4 * 8 * H * W * e                      # algorithmic bytes of one expansion launch
     expand_s = prof["expand_ms"] / 1e3 / max(prof["expand_launches"], 1)
