@@ -74,12 +74,30 @@ def cpu_baseline(layout_rows, length, seconds=12.0, layname=None):
         if time.perf_counter() - t0 > seconds:
             break
     dt = time.perf_counter() - t0
+    # the same port on several host cores at once (one BatchEnv per thread; the C call releases the GIL): a fairer CPU figure
+    # than one scalar core.  The pool is sized to the GPU box's CPU share for one GPU (16), not to its core count.
+    import concurrent.futures as cf
+    n_thr = max(1, min(16, os.cpu_count() or 1))
+
+    def worker(seed):
+        e2 = O.BatchEnv(layout_rows, n, length=length, auto_reset=True)
+        a2 = np.random.RandomState(seed).randint(0, 5, size=(64, n, 4)).astype(np.int8)
+        o2 = np.zeros((n, 4, 8, e2.L.H, e2.L.W), np.float32)
+        t1, k = time.perf_counter(), 0
+        while time.perf_counter() - t1 < 5.0:
+            for j in range(16):
+                e2.tick(a2[(k + j) % 64], o2)
+            k += 16
+        return n * k / (time.perf_counter() - t1)
+    with cf.ThreadPoolExecutor(n_thr) as ex:
+        mt = float(sum(ex.map(worker, range(n_thr))))
     ratio = reference_ratio(layname)
     derived = {} if ratio is None else {
         "reference_equiv_derived": n * ticks / dt / ratio,
         "derived_note": f"port figure / {ratio:.0f} = the port-to-reference speed ratio on one core of the build container "
                         "(tools/time_reference.py, profiles/r01_cpu_reference_ratio.json); derived, not measured here"}
     return {"value": n * ticks / dt, "unit": "env-steps/s", "cores": 1, "kind": "port", **derived,
+            "multi_thread": {"value": mt, "unit": "env-steps/s", "cores": n_thr, "sample": f"{n} envs per thread, 5 s"},
             "sample": f"{n} envs x {ticks} ticks of the same layout, float32 planes, auto-reset, uniform random actions "
                       f"({dt:.1f} s on 1 of {os.cpu_count()} host cores)"}
 
