@@ -697,14 +697,32 @@ __device__ __forceinline__ void stream_or_row(uint32_t *T, uint32_t off, uint32_
 //      32-bit word), expands it and issues one non-temporal dwordx4 store: the wave writes 1 KiB of consecutive
 //      addresses per instruction.  LDS operations of one wavefront execute in order, so no barrier is needed.
 // ---------------------------------------------------------------------------------------------------------------
-template <int DT, bool NT>
+// LUT: the 16 output bytes of a lane come from a block-shared lookup table indexed by its stream bits (float32: 16 entries
+// of 16 bytes, every entry in its own four LDS banks, so any mix of indices is conflict free; bfloat16: 256 entries; uint8: two
+// 8-bit look-ups of 8 bytes) instead of being computed: with the observation buffer partly resident in the Infinity Cache the
+// float32 kernel had become instruction bound (~1.8 T elements/s whatever the footprint), and the expansion arithmetic was most
+// of its ~35 instructions per 16 bytes.
+template <int DT, bool NT, bool LUT>
 __global__ __launch_bounds__(PMX_BLOCK) void pmx_expand_kernel(PmxExpandParams p)
 {
     constexpr int VEC = ObsVec<DT>::VEC;
     __shared__ uint32_t tab[4][8 * 32 * 32 / 32 + 8];
+    __shared__ __align__(16) uint32_t lut[LUT ? (DT == 0 ? 16 * 4 : (DT == 1 ? 256 * 4 : 256 * 2)) : 4];
+    if (LUT) {
+        const uint32_t i = threadIdx.x;
+        if (DT == 0) {
+            if (i < 16) *reinterpret_cast<uint4 *>(&lut[4 * i]) = pack_obs<0>(i);
+        } else if (DT == 1) {
+            *reinterpret_cast<uint4 *>(&lut[4 * i]) = pack_obs<1>(i);
+        } else {
+            lut[2 * i] = ((i & 15u) * 0x00204081u) & 0x01010101u;
+            lut[2 * i + 1] = ((i >> 4) * 0x00204081u) & 0x01010101u;
+        }
+        __syncthreads();
+    }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int W = p.lay->W, H = p.lay->H;
+    const int W = p.lay_W, H = p.lay_H;
     const int HW = H * W;
     const long total = (long)p.N * p.n_emit;
     long blk = p.reverse ? (long)gridDim.x - 1 - (long)blockIdx.x : (long)blockIdx.x;
@@ -766,7 +784,18 @@ __global__ __launch_bounds__(PMX_BLOCK) void pmx_expand_kernel(PmxExpandParams p
     for (int k = lane; k < n_vec; k += 64) {
         const uint32_t e0 = (uint32_t)k * VEC;
         const uint32_t bits = T[e0 >> 5] >> (e0 & 31);
-        uint4 v = pack_obs<DT>(bits);
+        uint4 v;
+        if (LUT) {
+            if (DT == 0) v = *reinterpret_cast<const uint4 *>(&lut[(bits & 15u) * 4]);
+            else if (DT == 1) v = *reinterpret_cast<const uint4 *>(&lut[(bits & 255u) * 4]);
+            else {
+                const uint2 lo = *reinterpret_cast<const uint2 *>(&lut[(bits & 255u) * 2]);
+                const uint2 hi = *reinterpret_cast<const uint2 *>(&lut[((bits >> 8) & 255u) * 2]);
+                v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+        } else {
+            v = pack_obs<DT>(bits);
+        }
         const uint32_t d = (uint32_t)(fself - (int)e0);
         if (d < (uint32_t)VEC) patch_self<DT>(v, (int)d, carry);
         if (NT) {   // streaming stores (merged into one dwordx4 nt): used when the planes exceed the Infinity Cache
@@ -862,10 +891,16 @@ extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, int dtype, hip
     PmxExpandParams q = *p;
     if (nt) q.reverse = 0;
     p = &q;
+    bool use_lut = true;
+    if (const char *o = getenv("PMX_EXPAND_LUT")) use_lut = atoi(o) != 0;    // experiment override
+#define PMX_EXPAND_LAUNCH2(DT, NTV, LUTV)                                                                               \
+    do {                                                                                                                \
+        if (ev0) hipExtLaunchKernelGGL((pmx_expand_kernel<DT, NTV, LUTV>), dim3(blocks), dim3(PMX_BLOCK), (uint32_t)lds_pad, st, ev0, ev1, 0, *p); \
+        else hipLaunchKernelGGL((pmx_expand_kernel<DT, NTV, LUTV>), dim3(blocks), dim3(PMX_BLOCK), lds_pad, st, *p);      \
+    } while (0)
 #define PMX_EXPAND_LAUNCH1(DT, NTV)                                                                                     \
     do {                                                                                                                \
-        if (ev0) hipExtLaunchKernelGGL((pmx_expand_kernel<DT, NTV>), dim3(blocks), dim3(PMX_BLOCK), (uint32_t)lds_pad, st, ev0, ev1, 0, *p); \
-        else hipLaunchKernelGGL((pmx_expand_kernel<DT, NTV>), dim3(blocks), dim3(PMX_BLOCK), lds_pad, st, *p);            \
+        if (use_lut) PMX_EXPAND_LAUNCH2(DT, NTV, true); else PMX_EXPAND_LAUNCH2(DT, NTV, false);                        \
     } while (0)
 #define PMX_EXPAND_LAUNCH(DT)                                                                                           \
     do {                                                                                                                \
