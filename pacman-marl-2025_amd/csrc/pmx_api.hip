@@ -254,10 +254,12 @@ int pmx_create(const pmx_config *cfg, pmx_env **out)
         int rc = build_layout(cfg, li, env->layouts[li]);
         if (rc != PMX_OK) { delete env; return rc; }
     }
-    const std::vector<int8_t> dump = dump_order(std::max(W, H));
+    std::vector<int8_t> dump = dump_order(std::max(W, H));
+    const size_t n_dump_real = dump.size() / 2;
+    while ((dump.size() / 2) % 4 != 0 || dump.size() / 2 < n_dump_real + 4) dump.push_back(127);   // the kernel reads groups of four: out-of-board filler
     size_t dist_bytes = 0;
     for (auto &l : env->layouts) {
-        l.dev.n_dump = (int)(dump.size() / 2);
+        l.dev.n_dump = (int)n_dump_real;
         l.dev.n_cells = (int)(l.cells.size() / 2);
         l.dev.dist_off = (uint32_t)dist_bytes;
         dist_bytes += (size_t)l.dev.n_cells * l.dev.n_cells;
@@ -292,7 +294,7 @@ int pmx_create(const pmx_config *cfg, pmx_env **out)
     std::vector<PmxLayoutDev> recs;
     for (auto &l : env->layouts) recs.push_back(l.dev);
     if (e == hipSuccess) e = hipMalloc((void **)&env->lay_dev, sizeof(PmxLayoutDev) * recs.size());
-    if (e == hipSuccess) e = hipMalloc((void **)&env->dump_dev, dump.size());
+    if (e == hipSuccess) e = hipMalloc((void **)&env->dump_dev, dump.size() + 8);   // read as aligned 32-bit words
     if (e == hipSuccess) e = hipMalloc((void **)&env->state_dev, PMX_STATE_WORDS(H) * N * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&env->snap_dev, 3 * (size_t)PMX_SNAP_WORDS(H) * N * sizeof(uint32_t));
     if (e == hipSuccess && n_layouts > 1) e = hipMalloc((void **)&env->layout_idx_dev, N * sizeof(int32_t));

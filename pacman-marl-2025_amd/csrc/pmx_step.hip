@@ -46,6 +46,7 @@ struct Ctx {
     uint32_t rng_key;     // seed ^ env * 0x9E3779B1 (the per-env part of the random-legal key)
     uint32_t start_xy[4]; // start cells, packed like Env::xy
     uint32_t *fd2;        // LDS: scratch food column for the reflex bots' what-if successors
+    uint32_t *fd3;        // LDS: scratch column of dump_food (rows of cells that cannot take a pellet)
     const uint8_t *dist;  // this env's layout's maze-distance matrix (or NULL)
     const int16_t *cidx;  // its cell -> matrix row map
     int n_cells;
@@ -102,19 +103,50 @@ __device__ __forceinline__ void dump_food(Env &e, const Ctx &c, uint32_t who_xy,
 {
     const int who_x = who_xy & 0xFF, who_y = who_xy >> 8;
     const int side_red = 2 * who_x < c.W;
-    for (int k = 0; k < c.n_dump && num > 0; ++k) {
-        int X = who_x + c.dump[2 * k], Y = who_y + c.dump[2 * k + 1];
-        if (X <= 0 || Y <= 0 || X >= c.W || Y >= c.H) continue;          // :609
-        if ((c.wl[Y * c.wls] >> X) & 1u) continue;                                // :612
-        uint32_t row = c.fd[Y * PMX_RULE_BLOCK];
-        if ((row >> X) & 1u) continue;                                    // :614
-        if ((2 * X < c.W) != side_red) continue;                          // :618
-        const uint32_t key = (uint32_t)X | ((uint32_t)Y << 8);
-        if (cap_find(e, key) >= 0) continue;                              // :621
-        if (e.xy[0] == key || e.xy[1] == key || e.xy[2] == key || e.xy[3] == key) continue;   // :625-627
-        c.fd[Y * PMX_RULE_BLOCK] = row | (1u << X);
-        --num;
-        if (X < c.half) ++d_red; else ++d_blue;
+    // Three things keep this rare path short (a tick in which some env dumps food used to be 4 us slower than one without,
+    // and with 16 k envs in lock-step most ticks have one): (1) the table index is wave-uniform, so the entries come through
+    // the scalar cache (constant address space) -- a vector load costs an L2 round trip per candidate AND waits for the
+    // snapshot stores in front of it (stores share vmcnt with loads on gfx9); (2) every test of capture.py:604-629 except
+    // "inside the rows" is folded once into per-row masks of cells that cannot take a pellet (LDS scratch column fd3), so a
+    // candidate costs one row read and one bit test; (3) candidates are taken four at a time (one LDS round trip per group)
+    // and judged strictly in order; a pellet is placed with an LDS OR (a cell occurs once in the visit order).
+    typedef const uint32_t __attribute__((address_space(4))) *const_words_t;
+    const const_words_t dwords = (const_words_t)(uintptr_t)c.dump;
+    // rows of cells that cannot take a pellet: walls, food, the other side (2x < W decides, :618), the border columns x = 0 and
+    // x >= W (:609), capsules (:621) and agents (:625-627); row 0 and rows >= H are rejected by the index test below
+    const uint32_t inner = (c.W >= 32 ? 0xFFFFFFFFu : ((1u << c.W) - 1u)) & ~1u;
+    const uint32_t red_cols = (1u << ((c.W + 1) >> 1)) - 1u;                  // x with 2x < W
+    const uint32_t allowed = inner & (side_red ? red_cols : ~red_cols);
+    c.fd3[0] = 0xFFFFFFFFu;
+    for (int y = 1; y < c.H; ++y) c.fd3[y * PMX_RULE_BLOCK] = c.wl[y * c.wls] | c.fd[y * PMX_RULE_BLOCK] | ~allowed;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) atomicOr(&c.fd3[(e.xy[i] >> 8) * PMX_RULE_BLOCK], 1u << (e.xy[i] & 0xFF));
+    if ((e.capw[0] & e.capw[1]) != 0xFFFFFFFFu) {
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            const uint32_t cxy = ((sl < 2 ? e.capw[0] : e.capw[1]) >> (16 * (sl & 1))) & 0xFFFFu;
+            if (cxy != 0xFFFFu) atomicOr(&c.fd3[(cxy >> 8) * PMX_RULE_BLOCK], 1u << (cxy & 0xFF));
+        }
+    }
+    for (int k = 0; k < c.n_dump && num > 0; k += 4) {
+        const uint32_t w0 = dwords[k >> 1], w1 = dwords[(k >> 1) + 1];      // the table is padded with out-of-board offsets
+        int X[4], Y[4];
+        bool inb[4];
+        uint32_t brow[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t ent = ((j < 2 ? w0 : w1) >> (16 * (j & 1))) & 0xFFFFu;
+            X[j] = who_x + (int)(int8_t)(ent & 0xFF); Y[j] = who_y + (int)(int8_t)(ent >> 8);
+            inb[j] = (uint32_t)Y[j] < (uint32_t)c.H && (uint32_t)X[j] < 32u;
+            brow[j] = c.fd3[(inb[j] ? Y[j] : 0) * PMX_RULE_BLOCK];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (num <= 0 || !inb[j] || ((brow[j] >> X[j]) & 1u)) continue;
+            atomicOr(&c.fd[Y[j] * PMX_RULE_BLOCK], 1u << X[j]);
+            --num;
+            if (X[j] < c.half) ++d_red; else ++d_blue;
+        }
     }
 }
 
@@ -485,6 +517,7 @@ __device__ __forceinline__ Ctx make_ctx(const PmxTickParams &p, uint32_t *lds)
     c.wls = multi ? PMX_RULE_BLOCK : 1;
     c.fd = lds + 32 + threadIdx.x;
     c.fd2 = multi ? lds + 32 + 2 * PMX_MAX_H_LDS * PMX_RULE_BLOCK + threadIdx.x : lds + 32 + c.H * PMX_RULE_BLOCK + threadIdx.x;
+    c.fd3 = multi ? lds + 32 + 3 * PMX_MAX_H_LDS * PMX_RULE_BLOCK + threadIdx.x : lds + 32 + 2 * c.H * PMX_RULE_BLOCK + threadIdx.x;
     c.dist = p.dist ? p.dist + c.L->dist_off : nullptr;
     c.cidx = p.cell_index ? p.cell_index + (size_t)(c.L - p.lay) * 1024 : nullptr;
     c.n_cells = c.L->n_cells;
@@ -507,7 +540,7 @@ __device__ __forceinline__ Ctx make_ctx(const PmxTickParams &p, uint32_t *lds)
 
 }  // namespace
 
-// dynamic LDS: 32 wall rows + H food rows x PMX_RULE_BLOCK lanes
+// dynamic LDS: 32 wall rows + 3 x H rows x PMX_RULE_BLOCK lanes (food, bots' scratch copy, dump_food's blocked-cell rows)
 template <bool BOTS, int HB>
 __global__ __launch_bounds__(PMX_RULE_BLOCK) void pmx_rule_kernel(PmxTickParams p)
 {
@@ -815,7 +848,7 @@ __global__ __launch_bounds__(PMX_BLOCK) void pmx_expand_kernel(PmxExpandParams p
 extern "C" hipError_t pmx_launch_rule(const PmxTickParams *p, int H, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1)
 {
     const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
-    const size_t lds = (p->layout_idx ? 32 + (size_t)(2 * PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)2 * H * PMX_RULE_BLOCK) * sizeof(uint32_t);
+    const size_t lds = (p->layout_idx ? 32 + (size_t)(3 * PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)3 * H * PMX_RULE_BLOCK) * sizeof(uint32_t);
     // row loops unrolled for the board-height bucket (see load_env_issue)
     const int hb = H <= 12 ? 12 : (H <= 16 ? 16 : (H <= 20 ? 20 : 32));
 #define PMX_RULE_LAUNCH(B, HBV)                                                                                         \
@@ -837,7 +870,7 @@ extern "C" hipError_t pmx_launch_rule(const PmxTickParams *p, int H, hipStream_t
 extern "C" hipError_t pmx_launch_rule_agent(const PmxTickParams *p, int H, int agent, hipStream_t st)
 {
     const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
-    const size_t lds = (p->layout_idx ? 32 + (size_t)(2 * PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)2 * H * PMX_RULE_BLOCK) * sizeof(uint32_t);
+    const size_t lds = (p->layout_idx ? 32 + (size_t)(3 * PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)3 * H * PMX_RULE_BLOCK) * sizeof(uint32_t);
     if (p->dist) hipLaunchKernelGGL(pmx_rule_agent_kernel<true>, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p, agent);
     else hipLaunchKernelGGL(pmx_rule_agent_kernel<false>, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p, agent);
     return hipGetLastError();
@@ -846,7 +879,7 @@ extern "C" hipError_t pmx_launch_rule_agent(const PmxTickParams *p, int H, int a
 extern "C" hipError_t pmx_launch_successor(const PmxTickParams *p, int H, int agent, hipStream_t st)
 {
     const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
-    const size_t lds = (p->layout_idx ? 32 + (size_t)(2 * PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)2 * H * PMX_RULE_BLOCK) * sizeof(uint32_t);
+    const size_t lds = (p->layout_idx ? 32 + (size_t)(3 * PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)3 * H * PMX_RULE_BLOCK) * sizeof(uint32_t);
     hipLaunchKernelGGL(pmx_successor_kernel, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p, agent);
     return hipGetLastError();
 }
@@ -854,7 +887,7 @@ extern "C" hipError_t pmx_launch_successor(const PmxTickParams *p, int H, int ag
 extern "C" hipError_t pmx_launch_reset(const PmxTickParams *p, int H, hipStream_t st)
 {
     const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
-    const size_t lds = (p->layout_idx ? 32 + (size_t)(2 * PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)2 * H * PMX_RULE_BLOCK) * sizeof(uint32_t);
+    const size_t lds = (p->layout_idx ? 32 + (size_t)(3 * PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)3 * H * PMX_RULE_BLOCK) * sizeof(uint32_t);
     hipLaunchKernelGGL(pmx_reset_kernel, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p);
     return hipGetLastError();
 }
