@@ -55,7 +55,7 @@ def canonicalize_obs(o):
 class VecMAPPOTrainer:
     def __init__(self, layout, n_envs, horizon=32, minibatch=512, epochs=UPDATE_EPOCHS, obs_dtype="bfloat16",
                  device="cuda:0", seed=0, rank=0, world_size=1, process_group=None, total_updates=2000, length=300,
-                 use_autocast=True, opponent="random", use_graph=False, algorithm="mappo", paired_minibatches=True, flat_bf16=False):
+                 use_autocast=True, opponent="random", use_graph=False, algorithm="mappo", paired_minibatches=True, flat_bf16=False, curriculum_scale=1.0):
         self.device = torch.device(device)
         self.rank, self.world_size = rank, world_size
         self.env = PmxVecEnv(layout, n_envs, length=length, reward_forLegalAction=True, defenceReward=True,
@@ -68,6 +68,9 @@ class VecMAPPOTrainer:
         # IPPO, so this variant has no parity target -- SURVEY section 0)
         assert algorithm in ("mappo", "ippo")
         self.algorithm = algorithm
+        # the reference's curriculum switches phases at updates 200 and 800 of 2 048 ticks each; a vectorised update holds
+        # n_envs * horizon ticks, so the thresholds can be compressed (curriculum_scale 0.1 -> updates 20 and 80)
+        self.curriculum_scale = float(curriculum_scale)
         # paired_minibatches: a minibatch is drawn as (env-tick) PAIRS, both learners of a pair together, so that the
         # centralised critic runs once per pair instead of once per agent sample (its input is the same merged observation
         # for both).  Every epoch is still a random permutation that visits each sample once and the loss of a minibatch is
@@ -144,9 +147,9 @@ class VecMAPPOTrainer:
         if mode == "curriculum":
             # :396-438 with the opponents this build has on the GPU: randomTeam first, then randomTeam / baselineTeam
             # (the reference weights its "hard" teams, baselineTeam among them, 5x), then 40 % self / 20 % pool / 40 % bots
-            if self.update_idx <= 200:
+            if self.update_idx <= 200 * self.curriculum_scale:
                 mode = "random"
-            elif self.update_idx <= 800:
+            elif self.update_idx <= 800 * self.curriculum_scale:
                 mode = "baseline" if self.np_rng.rand() < 5.0 / 6.0 else "random"
             else:
                 r = self.np_rng.rand()

@@ -28,6 +28,7 @@ ap.add_argument("--save", default="")
 ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--unpaired", action="store_true", help="the reference's independent shuffle of agent samples (critic runs per sample)")
 ap.add_argument("--flat-bf16", action="store_true", help="optimizer step on one flat bfloat16 weight copy instead of autocast")
+ap.add_argument("--curriculum-scale", type=float, default=1.0, help="compress the curriculum's phase thresholds (updates 200 / 800)")
 ap.add_argument("--graph", action="store_true", help="replay the optimizer step from a hipGraph (launch-bound minibatches, e.g. 512)")
 args = ap.parse_args()
 
@@ -57,7 +58,7 @@ def emit(rec):
 
 tr = trainer.VecMAPPOTrainer(layout, args.envs, horizon=args.horizon, minibatch=args.minibatch, epochs=args.epochs,
                              obs_dtype=args.obs, device=f"cuda:{local}", seed=args.seed, rank=rank, world_size=world,
-                             total_updates=args.total_updates, opponent=args.opponent, algorithm=args.algorithm, use_graph=args.graph, paired_minibatches=not args.unpaired, flat_bf16=args.flat_bf16)
+                             total_updates=args.total_updates, opponent=args.opponent, algorithm=args.algorithm, use_graph=args.graph, paired_minibatches=not args.unpaired, flat_bf16=args.flat_bf16, curriculum_scale=args.curriculum_scale)
 for u in range(args.updates):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     st = tr.train_update()
