@@ -6,8 +6,10 @@
 //                      test of gymPacMan.py:261-270.  Food rows live in LDS (one column per lane, conflict free),
 //                      agents in registers.  It leaves the state after each sub-step as a coalesced SoA snapshot.
 //   pmx_expand_kernel  one WAVEFRONT per (env, agent): turns a snapshot into the 8 observation planes of
-//                      gymPacMan.get_Observation (gymPacMan.py:195-229) with 16-byte-per-lane streaming stores.
-//                      This kernel moves >95 % of the bytes of the tick and is the HBM-roofline kernel.
+//                      gymPacMan.get_Observation (gymPacMan.py:195-229) with 16-byte-per-lane stores (ordinary while the
+//                      planes can live in the Infinity Cache, walking the blocks in alternating directions from tick to
+//                      tick; streaming with capped occupancy beyond).  This kernel moves >95 % of the bytes of the tick
+//                      and is the HBM-roofline kernel.
 // The split keeps the divergent integer rule logic at 64 envs per wave while the byte-heavy expansion gets
 // N*4 wavefronts of perfectly coalesced stores regardless of N.
 #include <cstdlib>
@@ -727,8 +729,9 @@ __device__ __forceinline__ void stream_or_row(uint32_t *T, uint32_t off, uint32_
 //      plane is a per-layout constant copied from the layout record, the food planes are OR-ed in row by row
 //      (H lanes), self / ally / enemies / capsules are single bits (8 lanes);
 //   2. every lane then reads ONE aligned stream word per 16 output bytes (a 4/8/16-bit field never straddles a
-//      32-bit word), expands it and issues one non-temporal dwordx4 store: the wave writes 1 KiB of consecutive
-//      addresses per instruction.  LDS operations of one wavefront execute in order, so no barrier is needed.
+//      32-bit word), turns its bits into the 16 bytes through a block-shared look-up table and issues one dwordx4
+//      store: the wave writes 1 KiB of consecutive addresses per instruction.  LDS operations of one wavefront
+//      execute in order, so the waves need no barrier after the one that publishes the look-up table.
 // ---------------------------------------------------------------------------------------------------------------
 // LUT: the 16 output bytes of a lane come from a block-shared lookup table indexed by its stream bits (float32: 16 entries
 // of 16 bytes, every entry in its own four LDS banks, so any mix of indices is conflict free; bfloat16: 256 entries; uint8: two
