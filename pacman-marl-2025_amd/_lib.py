@@ -10,6 +10,7 @@ PMX_MAX_DIM = 32
 OBS_F32, OBS_BF16, OBS_U8 = 0, 1, 2
 ACTION_RANDOM_LEGAL = -2
 ACTION_BASELINE_OFFENSE, ACTION_BASELINE_DEFENSE = -3, -4
+COLSUM_BLOCKS = 512
 LN32_PARTIAL_ROWS = 2048
 
 
@@ -67,6 +68,7 @@ PROTOTYPES = [
     ("pmx_gn8cl_gelu_backward", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _I32, _I32, _VP]),
     ("pmx_attn8_forward", C.c_int, [_VP, _VP, _VP, _I32, _I32, _VP]),
     ("pmx_attn8_backward", C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _VP]),
+    ("pmx_colsum_bf16", C.c_int, [_VP, C.c_int64, _I32, _VP, _VP]),
     ("pmx_canonicalize_obs", C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _VP]),
     ("pmx_merge_obs", C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
 ]

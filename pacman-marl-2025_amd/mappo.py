@@ -123,6 +123,21 @@ def attention8(qkv):
     return _Attention8.apply(qkv)
 
 
+def column_sums(t):
+    """t.sum over all but the last dimension, in float32: the HIP column-sum kernel for a contiguous bfloat16 tensor on the
+    GPU whose last dimension is a multiple of 8 (<= 256), torch's reduction otherwise."""
+    C_ = t.shape[-1]
+    if t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() and C_ % 8 == 0 and 8 <= C_ <= 256 and t.numel() >= C_ * 4096:
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        partial = torch.empty(_lib.COLSUM_BLOCKS, C_, dtype=torch.float32, device=t.device)
+        st = C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+        _lib.check(lib.pmx_colsum_bf16(t.data_ptr(), t.numel() // C_, C_, partial.data_ptr(), st), "pmx_colsum_bf16")
+        return partial.sum(0)
+    return t.reshape(-1, C_).float().sum(0)
+
+
 _DEBUG_KEEP = None    # tools/graph_debug.py: keeps (grad_out, bias_grad, weight_grad) of every token_linear backward alive
 
 
@@ -141,7 +156,7 @@ class _TokenLinear(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         gx = gy.matmul(weight.to(gy.dtype)) if ctx.needs_input_grad[0] else None
         gw = torch.bmm(gy.transpose(1, 2), x.to(gy.dtype)).sum(0).to(weight.dtype) if ctx.needs_input_grad[1] else None
-        gb = gy.sum((0, 1)).to(weight.dtype) if ctx.needs_input_grad[2] else None
+        gb = column_sums(gy).to(weight.dtype) if ctx.needs_input_grad[2] else None
         if _DEBUG_KEEP is not None:
             _DEBUG_KEEP.append((gy, gb, gw))
         return gx, gw, gb

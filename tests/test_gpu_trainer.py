@@ -179,6 +179,18 @@ def test_flat_bf16_step_tracks_autocast_step():
     assert torch.equal(lb._w16.detach().float(), lb.bucket.data.to(torch.bfloat16).float())
 
 
+@pytest.mark.parametrize("rows,C", [(154 * 257, 96), (154 * 64, 32), (70000, 128), (5000, 8), (4099, 256)])
+def test_column_sum_kernel_matches_torch(rows, C):
+    """pmx_colsum_bf16 (bias gradients of the token linears) against a float64 sum of the same bfloat16 values."""
+    from pmx import mappo
+    torch.manual_seed(rows + C)
+    x = (torch.randn(rows, C, device="cuda") * 0.7 + 0.1).to(torch.bfloat16)
+    got = mappo.column_sums(x.view(rows // 1, 1, C) if rows % 2 else x)
+    ref = x.double().sum(0)
+    assert got.dtype == torch.float32 and got.shape == (C,)
+    assert float((got.double() - ref).abs().max()) <= 2e-5 * float(x.double().abs().sum(0).max())
+
+
 def test_unpaired_minibatches_still_run():
     """paired_minibatches=False is the reference's independent shuffle of agent samples."""
     from pmx import trainer
