@@ -135,7 +135,7 @@ def column_sums(t):
         st = C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
         _lib.check(lib.pmx_colsum_bf16(t.data_ptr(), t.numel() // C_, C_, partial.data_ptr(), st), "pmx_colsum_bf16")
         return partial.sum(0)
-    return t.reshape(-1, C_).float().sum(0)
+    return t.sum(dim=tuple(range(t.dim() - 1)), dtype=torch.float32)
 
 
 _DEBUG_KEEP = None    # tools/graph_debug.py: keeps (grad_out, bias_grad, weight_grad) of every token_linear backward alive
