@@ -135,6 +135,8 @@ def column_sums(t):
         st = C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
         _lib.check(lib.pmx_colsum_bf16(t.data_ptr(), t.numel() // C_, C_, partial.data_ptr(), st), "pmx_colsum_bf16")
         return partial.sum(0)
+    if t.dim() == 1:
+        return t.float()
     return t.sum(dim=tuple(range(t.dim() - 1)), dtype=torch.float32)
 
 
