@@ -1,202 +1,178 @@
-"""Random capture mazes on the host: mazeGenerator.py restated with the same stdlib `random` call order.
+"""Random capture mazes on the host, bit-identical to what the reference's generator prints for a seed.
 
-The reference draws every random number from the GLOBAL `random` module after `random.seed(seed)`
-(mazeGenerator.py:255-264), so a maze is a pure function of the seed as long as the sequence of
-randint / random / gauss / choice / shuffle calls is the same.  This module reproduces that sequence on a private
-`random.Random(seed)` (CPython's Mersenne Twister and its derived methods are the same code), which leaves the
-caller's global stream alone; `generate_maze(seed, use_global=True)` reseeds the global module instead, for callers
-that rely on the reference's side effect on later bot choices ("RNG").
+Behaviour pinned by tests/golden/mazes.json (G5, captured from mazeGenerator.generateMaze, mazeGenerator.py:255-264).
+The reference draws from the GLOBAL `random` module after `random.seed(seed)`; a maze is therefore a pure function of
+the seed provided the randint / random / gauss / choice / shuffle calls happen in the same sequence.  This module keeps
+that sequence but not the reference's program: the half board is a flat byte array, rooms are plain
+(top, left, height, width) records on an explicit stack (no Maze objects, no recursion), and the full map is assembled
+once at the end.  Draws come from a private `random.Random(seed)` unless `use_global` asks for the reference's side
+effect on the caller's stream ("RNG").
 
-Pinned by tests/golden/mazes.json (G5).
+Reference quirks that shape the output and are kept on purpose:
+  * the "does this room touch the far border" test of a vertical wall compares ROW indices with the half board's
+    column count (and the horizontal one compares columns with the row count), mazeGenerator.py:96,110;
+  * the prison draw (randint, random) is consumed although no prison is ever built (:124-134);
+  * capsule columns are tested against the float centre c/2, food columns against the integer centre c//2 (:232,:246).
 """
 import random as _random
 
-W, F, C, E = "%", ".", "o", " "
-
-
-class _Maze:
-    """mazeGenerator.py:42-118"""
-
-    def __init__(self, rows, cols, anchor=(0, 0), root=None, rng=None):
-        self.r, self.c = rows, cols
-        self.grid = [[E for _ in range(cols)] for _ in range(rows)]
-        self.anchor = anchor
-        self.rooms = []
-        self.root = root if root is not None else self
-        self.rng = rng if rng is not None else self.root.rng
-
-    def to_map(self):   # :57-75 mirrored copy on the right, then a border
-        for row in range(self.r):
-            for col in range(self.c - 1, -1, -1):
-                self.grid[row].append(self.grid[row][col])
-        self.c *= 2
-        for row in range(self.r):
-            self.grid[row] = [W] + self.grid[row] + [W]
-        self.c += 2
-        self.grid.insert(0, [W for _ in range(self.c)])
-        self.grid.append([W for _ in range(self.c)])
-        self.r += 2
-
-    def __str__(self):
-        return "\n".join("".join(self.grid[row][col] for col in range(self.c)) for row in range(self.r))
-
-    def add_wall(self, i, gaps=1, vert=True):   # :85-118
-        add_r, add_c = self.anchor
-        root = self.root
-        if vert:
-            gaps = min(self.r, gaps)
-            slots = [add_r + x for x in range(self.r)]
-            if 0 not in slots:
-                if root.grid[min(slots) - 1][add_c + i] == E:
-                    slots.remove(min(slots))
-                if len(slots) <= gaps:
-                    return 0
-            if root.c - 1 not in slots and max(slots) + 1 < len(root.grid):
-                if root.grid[max(slots) + 1][add_c + i] == E:
-                    slots.remove(max(slots))
-            if len(slots) <= gaps:
-                return 0
-            self.rng.shuffle(slots)
-            for row in slots[int(round(gaps)):]:
-                root.grid[row][add_c + i] = W
-            self.rooms.append(_Maze(self.r, i, (add_r, add_c), root))
-            self.rooms.append(_Maze(self.r, self.c - i - 1, (add_r, add_c + i + 1), root))
-        else:
-            gaps = min(self.c, gaps)
-            slots = [add_c + x for x in range(self.c)]
-            if 0 not in slots:
-                if root.grid[add_r + i][min(slots) - 1] == E:
-                    slots.remove(min(slots))
-                if len(slots) <= gaps:
-                    return 0
-            if root.r - 1 not in slots and max(slots) + 1 < len(root.grid[0]):
-                if root.grid[add_r + i][max(slots) + 1] == E:
-                    slots.remove(max(slots))
-            if len(slots) <= gaps:
-                return 0
-            self.rng.shuffle(slots)
-            for col in slots[int(round(gaps)):]:
-                root.grid[add_r + i][col] = W
-            self.rooms.append(_Maze(i, self.c, (add_r, add_c), root))
-            self.rooms.append(_Maze(self.r - i - 1, self.c, (add_r + i + 1, add_c), root))
-        return 1
-
-
-def _make(room, depth, gaps=1, vert=True, min_width=1, gapfactor=0.5):   # :153-184
-    if room.r <= min_width and room.c <= min_width:
-        return
-    num = room.c if vert else room.r
-    if num < min_width + 2:
-        vert = not vert
-        num = room.c if vert else room.r
-    wall_slots = [num - 2] if depth == 0 else range(1, num - 1)
-    if len(wall_slots) == 0:
-        return
-    choice = room.rng.choice(wall_slots)
-    if not room.add_wall(choice, gaps, vert):
-        return
-    for sub in room.rooms:
-        _make(sub, depth + 1, max(1, gaps * gapfactor), not vert, min_width, gapfactor)
-
-
-def _make_with_prison(room, depth, gaps=1, vert=True, min_width=1, gapfactor=0.5):   # :120-151
-    rng = room.rng
-    rng.randint(0, 2)       # drawn and overwritten in the reference (:124)
-    rng.random()            # proll (:125); the result is discarded because p is forced to 0 (:134)
-    p = 0
-    add_r, add_c = room.anchor
-    room.rooms.append(_Maze(room.r, room.c - (2 * p), (add_r, add_c + (2 * p)), room.root))
-    for sub in room.rooms:
-        _make(sub, depth + 1, gaps, vert, min_width, gapfactor)
-    return 2 * p
-
-
-def _add_pacman_stuff(maze, max_food=60, max_capsules=4, toskip=0):   # :194-251
-    rng = maze.rng
-    max_depth = 2
-    depth = 0
-    total_food = 0
-    while True:
-        new_grid = [row[:] for row in maze.grid]
-        depth += 1
-        num_added = 0
-        for row in range(1, maze.r - 1):
-            for col in range(1 + toskip, (maze.c // 2) - 1):
-                if (row > maze.r - 6) and (col < 6):
-                    continue
-                if maze.grid[row][col] != E:
-                    continue
-                neighbors = ((maze.grid[row - 1][col] == E) + (maze.grid[row][col - 1] == E)
-                             + (maze.grid[row + 1][col] == E) + (maze.grid[row][col + 1] == E))
-                if neighbors == 1:
-                    new_grid[row][col] = F
-                    new_grid[row][maze.c - col - 1] = F
-                    num_added += 2
-                    total_food += 2
-        maze.grid = new_grid
-        if num_added == 0:
-            break
-        if depth >= max_depth:
-            break
-    maze.grid[1][1] = "3"
-    maze.grid[2][1] = "1"
-    maze.grid[1][maze.c - 2] = "4"
-    maze.grid[2][maze.c - 2] = "2"
-    total_capsules = 0
-    draws = 0
-    while total_capsules < max_capsules:
-        draws += 1
-        if draws > 200000:   # the reference loops forever when no cell qualifies (only possible for non-reference sizes)
-            raise ValueError("maze size leaves no legal capsule cell")
-        row = rng.randint(1, maze.r - 1)
-        col = rng.randint(1 + toskip, (maze.c // 2) - 2)
-        if (row > maze.r - 6) and (col < 6):
-            continue
-        if abs(col - maze.c / 2) < 3:
-            continue
-        if maze.grid[row][col] == E:
-            maze.grid[row][col] = C
-            maze.grid[row][maze.c - col - 1] = C
-            total_capsules += 2
-    draws = 0
-    while total_food < max_food:
-        draws += 1
-        if draws > 2000000:
-            raise ValueError("maze size leaves too few legal food cells")
-        row = rng.randint(1, maze.r - 1)
-        col = rng.randint(1 + toskip, (maze.c // 2) - 1)
-        if (row > maze.r - 6) and (col < 6):
-            continue
-        if abs(col - maze.c // 2) < 3:
-            continue
-        if maze.grid[row][col] == E:
-            maze.grid[row][col] = F
-            maze.grid[row][maze.c - col - 1] = F
-            total_food += 2
-
-
+WALL, OPEN, PELLET, POWER = 0x25, 0x20, 0x2E, 0x6F          # '%', ' ', '.', 'o'
 MAX_DIFFERENT_MAZES = 10000
 
 
+class _Half:
+    """The left half before mirroring: `cell[r * cols + c]`, row 0 at the top."""
+
+    __slots__ = ("rows", "cols", "cell")
+
+    def __init__(self, rows, cols):
+        self.rows, self.cols = rows, cols
+        self.cell = bytearray([OPEN]) * (rows * cols)
+
+    def is_open(self, r, c):
+        return self.cell[r * self.cols + c] == OPEN
+
+    def block(self, r, c):
+        self.cell[r * self.cols + c] = WALL
+
+
+def _split(half, rng, room, at, gaps, vertical):
+    """Draw one wall through `room` at offset `at`, leaving `gaps` openings; returns the two sub-rooms or None when the
+    wall would seal the room off (mazeGenerator.py:85-118 as behaviour: which cells end up walls, and when shuffle runs)."""
+    top, left, height, width = room
+    if vertical:
+        span, first, line = height, top, left + at
+        probe = lambda k: half.is_open(k, line)                  # cell of the wall's own column in row k
+        far_edge, limit = half.cols - 1, half.rows               # (sic) rows tested against the column count
+    else:
+        span, first, line = width, left, top + at
+        probe = lambda k: half.is_open(line, k)
+        far_edge, limit = half.rows - 1, half.cols
+    gaps = min(span, gaps)
+    run = list(range(first, first + span))
+    # a wall must not plug the opening of the wall it abuts: drop its end cell when the cell beyond that end is open
+    if first != 0:
+        if probe(first - 1):
+            run.pop(0)
+        if len(run) <= gaps:
+            return None
+    last = first + span - 1
+    if far_edge not in run and last + 1 < limit:
+        if probe(last + 1):
+            run.pop()
+    if len(run) <= gaps:
+        return None
+    rng.shuffle(run)
+    for k in run[int(round(gaps)):]:
+        if vertical:
+            half.block(k, line)
+        else:
+            half.block(line, k)
+    if vertical:
+        return (top, left, height, at), (top, left + at + 1, height, width - at - 1)
+    return (top, left, at, width), (top + at + 1, left, height - at - 1, width)
+
+
+def _carve(half, rng, gaps, gapfactor):
+    """Recursive division, depth first and first child first, as an explicit stack of (room, gaps, vertical)."""
+    todo = [((0, 0, half.rows, half.cols), gaps, True)]
+    while todo:
+        room, g, vertical = todo.pop()
+        _, _, height, width = room
+        if height <= 0 and width <= 0:
+            continue
+        extent = width if vertical else height
+        if extent < 2:                                           # too thin this way: cut it the other way
+            vertical = not vertical
+            extent = width if vertical else height
+        if extent <= 2:                                          # no interior line to put a wall on
+            continue
+        at = rng.choice(range(1, extent - 1))
+        parts = _split(half, rng, room, at, g, vertical)
+        if parts is None:
+            continue
+        g2 = max(1, g * gapfactor)
+        todo.append((parts[1], g2, not vertical))                # popped second
+        todo.append((parts[0], g2, not vertical))
+
+
+def _full_map(half):
+    """Mirror the half to the right and put a wall frame around it -> list of bytearray rows."""
+    width = 2 * half.cols + 2
+    rows = [bytearray([WALL]) * width]
+    for r in range(half.rows):
+        line = half.cell[r * half.cols:(r + 1) * half.cols]
+        rows.append(bytearray([WALL]) + line + line[::-1] + bytearray([WALL]))
+    rows.append(bytearray([WALL]) * width)
+    return rows
+
+
+def _dead_end_pellets(grid, skip):
+    """Up to two sweeps that put a pellet (and its mirror image) into every open left-half cell with exactly one open
+    neighbour; each sweep looks at the board as it was when the sweep began.  Returns the number of pellets placed."""
+    n_rows, n_cols = len(grid), len(grid[0])
+    placed = 0
+    for _ in range(2):
+        before = [bytes(r) for r in grid]
+        added = 0
+        for r in range(1, n_rows - 1):
+            for c in range(1 + skip, n_cols // 2 - 1):
+                if (r > n_rows - 6 and c < 6) or before[r][c] != OPEN:
+                    continue
+                exits = ((before[r - 1][c] == OPEN) + (before[r + 1][c] == OPEN) + (before[r][c - 1] == OPEN)
+                         + (before[r][c + 1] == OPEN))
+                if exits == 1:
+                    grid[r][c] = grid[r][n_cols - 1 - c] = PELLET
+                    added += 2
+        placed += added
+        if not added:
+            break
+    return placed
+
+
+def _scatter(grid, rng, glyph, want, have, col_hi, centre, skip, what):
+    """Rejection-sample left-half cells (mirrored to the right) until `want` glyphs are on the board."""
+    n_rows, n_cols = len(grid), len(grid[0])
+    tries = 0
+    while have < want:
+        tries += 1
+        if tries > 2000000:     # the reference spins forever when nothing qualifies (only possible for non-reference sizes)
+            raise ValueError(f"maze size leaves too few legal {what} cells")
+        r = rng.randint(1, n_rows - 1)
+        c = rng.randint(1 + skip, col_hi)
+        if (r > n_rows - 6 and c < 6) or abs(c - centre) < 3:
+            continue
+        if grid[r][c] == OPEN:
+            grid[r][c] = grid[r][n_cols - 1 - c] = glyph
+            have += 2
+    return have
+
+
 def generate_maze(seed=None, rows=18, cols=9, use_global=False):
-    """mazeGenerator.generateMaze (:255-264).  rows x cols is the half maze before mirroring and bordering; the
-    reference hard-codes Maze(18, 9), i.e. a 20 x 20 map.  Other sizes are a build-side extension with no reference
+    """The map text mazeGenerator.generateMaze(seed) returns.  rows x cols is the half board before mirroring and
+    framing; the reference hard-codes 18 x 9 (a 20 x 20 map).  Other sizes are a build-side extension with no reference
     counterpart (BASELINE config 5 names 32x16: rows=14, cols=15)."""
+    if not seed:
+        seed = _random.randint(1, MAX_DIFFERENT_MAZES)
     if use_global:
-        if not seed:
-            seed = _random.randint(1, MAX_DIFFERENT_MAZES)
         _random.seed(seed)
         rng = _random
     else:
-        if not seed:
-            seed = _random.randint(1, MAX_DIFFERENT_MAZES)
         rng = _random.Random(seed)
-    maze = _Maze(rows, cols, rng=rng)
+    half = _Half(rows, cols)
     gapfactor = rng.gauss(0.7, 0.2)
-    skip = _make_with_prison(maze, depth=0, gaps=5, vert=True, min_width=0, gapfactor=gapfactor)
-    maze.to_map()
-    _add_pacman_stuff(maze, 2 * (maze.r * maze.c // 20), 2, skip)
-    return str(maze)
+    rng.randint(0, 2)           # the prison draws: consumed, never used (see the module docstring)
+    rng.random()
+    skip = 0
+    _carve(half, rng, 5, gapfactor)
+    grid = _full_map(half)
+    n_rows, n_cols = len(grid), len(grid[0])
+    pellets = _dead_end_pellets(grid, skip)
+    for digit, (r, c) in zip(b"3142", ((1, 1), (2, 1), (1, n_cols - 2), (2, n_cols - 2))):
+        grid[r][c] = digit
+    _scatter(grid, rng, POWER, 2, 0, n_cols // 2 - 2, n_cols / 2, skip, "capsule")
+    _scatter(grid, rng, PELLET, 2 * (n_rows * n_cols // 20), pellets, n_cols // 2 - 1, n_cols // 2, skip, "food")
+    return "\n".join(r.decode("ascii") for r in grid)
 
 
 def random_layout(seed=None, use_global=True):
