@@ -235,6 +235,38 @@ int pmx_attn8_forward(const void *qkv_dev, void *out_dev, float *lse_dev, int32_
 int pmx_attn8_backward(const void *qkv_dev, const void *out_dev, const void *dout_dev, const float *lse_dev, void *dqkv_dev,
                        int32_t S, int32_t B, void *stream);
 
+/* ---- The actor's convolutional tower as one forward and one backward kernel ------------------------------------------
+ * MAPPOAgent.actor_backbone (pacman_mappo_resnet.py:104-113 with ResidualBlock :49-67):
+ *   conv3x3(8->16) GELU conv3x3(16->32) GELU 3 x [conv3x3 GroupNorm(4) GELU conv3x3 GroupNorm(4) (+x) GELU], bf16 matrix-core
+ *   products with fp32 accumulation, GroupNorm and GELU in fp32 on the bf16-rounded convolution output (what bf16 autocast
+ *   computes).  Boards whose padded area H*(W+2) needs 10 or 11 position tiles of 16 are supported (tinyCapture,
+ *   smallCapture); pmx_actor_supported() says so and callers keep the library convolutions for the rest.
+ * Parameters arrive as float32 device pointers in nn.Module order: conv_w[l] is [cout][cin][3][3], l = 0,1 the stem, then
+ * conv1 / conv2 of the three blocks; gn_w / gn_b [6][32] are gn1, gn2 of the three blocks. */
+typedef struct {
+    const float *conv_w[8];
+    const float *conv_b[8];
+    const float *gn_w[6];
+    const float *gn_b[6];
+} pmx_actor_params;
+#define PMX_ACTOR_PACK_BYTES 297984    /* bf16 operand fragments of the 8 layers (forward + input-gradient order) + fp32 biases / GroupNorm affine */
+#define PMX_ACTOR_GRAD_FLOATS 74496    /* backward's fp32 gradient buffer: weight-gradient tiles + bias / GroupNorm gradients */
+int pmx_actor_supported(int32_t H, int32_t W);
+/* bytes of the activation save area (training forward -> backward) and of backward's scratch, for B samples */
+int pmx_actor_sizes(int32_t H, int32_t W, int64_t B, int64_t *save_bytes, int64_t *scratch_bytes);
+/* parameters -> pack_dev [PMX_ACTOR_PACK_BYTES]; once per optimizer step (the weights changed) or once per rollout */
+int pmx_actor_pack(const pmx_actor_params *params, void *pack_dev, void *stream);
+/* obs_dev [B][8][H][W] of PMX_OBS_* elements -> feat_dev [B][H*W][32] bfloat16 (channels-last; the reference's nn.Flatten order
+ * is the transpose of the last two dimensions).  save_dev NULL = inference (scratch_dev then holds the blocks' skip inputs
+ * between layers and is required); otherwise save_dev receives what backward needs and scratch_dev may be NULL. */
+int pmx_actor_forward(const void *obs_dev, int32_t obs_dtype, const void *pack_dev, void *feat_dev, void *save_dev,
+                      void *scratch_dev, int64_t B, int32_t H, int32_t W, void *stream);
+/* dfeat_dev [B][H*W][32] bfloat16 -> grad_dev [PMX_ACTOR_GRAD_FLOATS] (zeroed and accumulated here, sum over the batch) */
+int pmx_actor_backward(const void *obs_dev, int32_t obs_dtype, const void *pack_dev, const void *save_dev, const void *dfeat_dev,
+                       void *scratch_dev, float *grad_dev, int64_t B, int32_t H, int32_t W, void *stream);
+/* grad_dev -> float32 gradients in the parameters' own shapes (the pointers of `out` are written, not read) */
+int pmx_actor_unpack_grads(const float *grad_dev, const pmx_actor_params *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,8 @@ ACTION_RANDOM_LEGAL = -2
 ACTION_BASELINE_OFFENSE, ACTION_BASELINE_DEFENSE = -3, -4
 COLSUM_BLOCKS = 512
 LN32_PARTIAL_ROWS = 2048
+ACTOR_PACK_BYTES = 297984
+ACTOR_GRAD_FLOATS = 74496
 
 
 class PmxError(RuntimeError):
@@ -38,6 +40,10 @@ class State(C.Structure):
     _fields_ = [("pos", (C.c_int8 * 2) * 4), ("dir", C.c_int8 * 4), ("pac", C.c_uint8 * 4), ("scared", C.c_uint8 * 4),
                 ("carry", C.c_uint16 * 4), ("ret", C.c_uint16 * 4), ("food", C.c_uint32 * PMX_MAX_DIM),
                 ("caps", C.c_uint32 * PMX_MAX_DIM), ("score", C.c_int32), ("steps", C.c_int32), ("ticks", C.c_uint32)]
+
+
+class ActorParams(C.Structure):
+    _fields_ = [("conv_w", C.c_void_p * 8), ("conv_b", C.c_void_p * 8), ("gn_w", C.c_void_p * 6), ("gn_b", C.c_void_p * 6)]
 
 
 # every symbol include/pmx.h declares: (name, restype, argtypes)
@@ -71,6 +77,12 @@ PROTOTYPES = [
     ("pmx_colsum_bf16", C.c_int, [_VP, C.c_int64, _I32, _VP, _VP]),
     ("pmx_canonicalize_obs", C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _VP]),
     ("pmx_merge_obs", C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
+    ("pmx_actor_supported", C.c_int, [_I32, _I32]),
+    ("pmx_actor_sizes", C.c_int, [_I32, _I32, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("pmx_actor_pack", C.c_int, [C.POINTER(ActorParams), _VP, _VP]),
+    ("pmx_actor_forward", C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, C.c_int64, _I32, _I32, _VP]),
+    ("pmx_actor_backward", C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, _VP, C.c_int64, _I32, _I32, _VP]),
+    ("pmx_actor_unpack_grads", C.c_int, [_VP, C.POINTER(ActorParams), _VP]),
 ]
 # test / bench hooks that are not part of the public header
 EXTRA = [
@@ -90,17 +102,22 @@ def load():
     if _lib is not None:
         return _lib
     path = lib_path()
-    if not os.path.exists(path) or _build.stale():
+    if _build.stale():
+        # the sources changed (or nothing was built yet): rebuild, and let a compile error surface -- a library built from
+        # other sources is never used in its place
         try:
             _build.build()
-        except Exception as e:  # no compiler on this machine: use the prebuilt file if there is one
-            if not os.path.exists(path):
-                raise PmxError(f"libpmx_hip.so is missing and could not be built ({e}); run "
-                               f"`python -c 'import __graft_entry__ as g; g.build()'` on a machine with hipcc") from e
+        except Exception as e:
+            raise PmxError(f"libpmx_hip.so is missing or out of date and could not be built ({e}); run "
+                           f"`python -c 'import __graft_entry__ as g; g.build()'` on a machine with hipcc") from e
     try:
         lib = C.CDLL(path)
     except OSError as e:
         raise PmxError(f"cannot load {path}: {e} (the product has no CPU fallback)") from e
+    lib.pmx_source_hash.restype = C.c_char_p
+    built_from = lib.pmx_source_hash().decode()
+    if built_from != _build.source_hash():
+        raise PmxError(f"{path} was built from other sources (hash {built_from}, tree {_build.source_hash()}): rebuild it")
     for name, res, args in PROTOTYPES + EXTRA:
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args

@@ -1,4 +1,9 @@
-"""Builds libpmx_hip.so (the C ABI of include/pmx.h + the gfx950 kernels) in-tree with hipcc."""
+"""Builds libpmx_hip.so (the C ABI of include/pmx.h + the gfx950 kernels) in-tree with hipcc.
+
+Every .hip source is compiled to its own object (in parallel, rebuilt only when it or a header is newer) and the objects
+are linked into the shared library; a hash of the sources is linked in as `pmx_source_hash()` so that a loader can
+tell a stale binary from the tree it sits in."""
+import hashlib
 import os
 import shutil
 import subprocess
@@ -6,10 +11,12 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpmx_hip.so")
-SOURCES = ["pmx_step.hip", "pmx_api.hip", "pmx_train.hip"]
+OBJDIR = os.path.join(HERE, "build")
+SOURCES = ["pmx_step.hip", "pmx_api.hip", "pmx_train.hip", "pmx_actor.hip"]
 HEADERS = ["pmx_device.h", os.path.join("..", "..", "include", "pmx.h")]
 # -ffp-contract=off: the float64 reward sums and the float32 GAE scan must round like the reference's Python/torch ops
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
+# (the network kernels opt back in per file with `#pragma clang fp contract(fast)`)
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 
 
 def hipcc():
@@ -19,12 +26,26 @@ def hipcc():
     raise RuntimeError("hipcc not found: the pmx HIP library cannot be built")
 
 
+def _deps():
+    return [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+
+
+def source_hash():
+    """sha256 over the kernel sources and headers (what pmx_source_hash() of a matching library returns, 16 hex digits)."""
+    h = hashlib.sha256()
+    for d in _deps()[:-1]:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def stale():
-    if not os.path.exists(LIB):
+    """True when the library is missing or was built from other sources than the ones in the tree (the hash of the
+    sources it was built from sits beside it; file times do not survive a copy to another machine)."""
+    if not os.path.exists(LIB) or not os.path.exists(LIB + ".hash"):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(LIB + ".hash") as f:
+        return f.read().strip() != source_hash()
 
 
 def build(force=False, verbose=False):
@@ -38,12 +59,33 @@ def build(force=False, verbose=False):
         try:
             if not force and not stale():          # another process built it while we waited
                 return LIB
+            cc = hipcc()
+            os.makedirs(OBJDIR, exist_ok=True)
+            hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+            hdr_t = max(hdr_t, os.path.getmtime(os.path.abspath(__file__)))
+            jobs, objs = [], []
+            for s in SOURCES:
+                src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s.replace(".hip", ".o"))
+                objs.append(obj)
+                if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+                    cmd = [cc] + CFLAGS + ["-c", src, "-o", obj]
+                    if verbose:
+                        print(" ".join(cmd))
+                    jobs.append((s, subprocess.Popen(cmd, cwd=CSRC)))
+            failed = [s for s, p in jobs if p.wait() != 0]
+            if failed:
+                raise RuntimeError("hipcc failed on " + ", ".join(failed))
+            stamp = os.path.join(OBJDIR, "pmx_stamp.cpp")
+            with open(stamp, "w") as f:
+                f.write('extern "C" const char *pmx_source_hash(void) { return "%s"; }\n' % source_hash())
             tmp = LIB + ".tmp.%d" % os.getpid()
-            cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+            cmd = [cc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + [stamp, "-o", tmp]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd, cwd=CSRC)
             os.replace(tmp, LIB)
+            with open(LIB + ".hash", "w") as f:
+                f.write(source_hash())
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB

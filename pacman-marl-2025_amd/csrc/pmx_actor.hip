@@ -1,0 +1,915 @@
+// pmx_actor.hip -- the actor's convolutional tower of MAPPOAgent (pacman_mappo_resnet.py:49-67, 104-113) as ONE forward
+// and ONE backward kernel for gfx950:
+//     conv3x3(8->16) GELU conv3x3(16->32) GELU  3 x [conv3x3 GN(4) GELU conv3x3 GN(4) (+x) GELU]
+// bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulation / GroupNorm / GELU.
+//
+// Mapping.  One WAVEFRONT owns one sample from the first convolution to the last; nothing is shared between waves, so
+// there is no barrier anywhere in the forward kernel.  A sample's activation lives in the wave's private LDS map as
+// [padded position][32 channels] bf16 (64 bytes per position, the 16-byte chunks XOR-swizzled with bit 2 of the position
+// so that the ds_read_b128 of an MFMA operand is bank-conflict free).  Positions are the linear index q = (row+1)*(W+2) +
+// (col+1) of the zero-padded board, so a 3x3 tap is a constant shift of q and a tile of 16 consecutive q is one MFMA
+// column block; the two pad columns inside a tile cost 2/16 of the work and are masked to zero on every write, which keeps
+// the padding zero for the next layer.  Every layer is run as 32 -> 32 channels (the stem's missing channels are zero
+// weights), which makes all eight layers one loop body:
+//     D[co][pos] += A[co][ci] (weights of one tap, 16 x 32)  x  B[ci][pos] (16 positions, one ds_read_b128 per lane)
+// The accumulator of a tile then holds, per lane, FOUR CONSECUTIVE CHANNELS of ONE position -- the same ownership in
+// every layer ("P layout": lane (p = lane & 15, g = lane >> 4), tile t, half m owns channels 16m + 4g .. +3 of position
+// 16t + p).  Bias, GroupNorm statistics (two shuffles levels over the 32 lanes of a group), the residual add (the block
+// input stays in registers, in P layout), exact GELU and the bf16 pack are therefore lane-local, and the result goes back
+// to the LDS map with one ds_write_b64.  Weights never touch LDS: a layer's 18 operand fragments (72 VGPRs) are loaded
+// from a pre-packed global buffer (L2-resident, 18 KB per layer) while the previous layer's epilogue runs.
+//
+// Training additionally dumps, per layer, the pre-activation (bf16-rounded convolution output) and the activation in P
+// layout (512 contiguous bytes per wave store), which is all the backward kernel needs; it walks the layers in reverse
+// with the same ownership: GELU' and the GroupNorm backward are lane-local again, the input gradient is the same
+// convolution loop with flipped weights, and the weight gradient contracts over POSITIONS, whose operands come out of the
+// very same [position][channel] maps through ds_read_b64_tr_b16 (the hardware transposing read).
+#pragma clang fp contract(fast)
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "../../include/pmx.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+constexpr int NLAYER = 8;
+constexpr int GUARD = 1;                       // map positions in front of padded index 0 (a tap reads q - WP - 1 >= -1)
+constexpr int FRAG_PER_LAYER = 2 * 9 * 64 * 8; // bf16 elements of one layer's operand fragments
+// byte offsets inside the packed-parameter buffer
+constexpr size_t PACK_FWD = 0;
+constexpr size_t PACK_BWD = PACK_FWD + (size_t)NLAYER * FRAG_PER_LAYER * 2;
+constexpr size_t PACK_BIAS = PACK_BWD + (size_t)NLAYER * FRAG_PER_LAYER * 2;
+constexpr size_t PACK_GNW = PACK_BIAS + NLAYER * 32 * 4;
+constexpr size_t PACK_GNB = PACK_GNW + NLAYER * 32 * 4;
+constexpr size_t PACK_BYTES = PACK_GNB + NLAYER * 32 * 4;
+static_assert(PACK_BYTES == PMX_ACTOR_PACK_BYTES, "include/pmx.h and pmx_actor.hip disagree on the pack size");
+// float offsets inside the gradient buffer
+constexpr int GRAD_W = 0;                      // [8][36 tiles][64 lanes][4]
+constexpr int GRAD_B = GRAD_W + NLAYER * 36 * 256;
+constexpr int GRAD_GNW = GRAD_B + NLAYER * 32;
+constexpr int GRAD_GNB = GRAD_GNW + NLAYER * 32;
+constexpr int GRAD_FLOATS = GRAD_GNB + NLAYER * 32;
+static_assert(GRAD_FLOATS == PMX_ACTOR_GRAD_FLOATS, "include/pmx.h and pmx_actor.hip disagree on the gradient size");
+
+__host__ __device__ constexpr int map_positions(int nt, int wp) { return GUARD + wp + 32 * ((nt + 1) / 2) + wp + 3; }
+
+// byte offset of 16-byte chunk `chunk` (channels 8*chunk .. +7) of map position `pos`
+__device__ __forceinline__ int map_off(int pos, int chunk) { return pos * 64 + ((chunk ^ ((pos >> 1) & 2)) << 4); }
+
+__device__ __forceinline__ uint32_t pack2(float a, float b)
+{
+    f32x2 f = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
+}
+__device__ __forceinline__ float lo_f(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float hi_f(uint32_t u) { return __uint_as_float(u & 0xFFFF0000u); }
+__device__ __forceinline__ float bf16_round(float v) { return lo_f(pack2(v, 0.0f)); }
+
+// Phi(z) = 0.5 (1 + erf(z / sqrt 2)) by Abramowitz-Stegun 7.1.26 (|error of erf| <= 1.5e-7) and e = exp(-z^2 / 2).
+// GELU(z) = z Phi(z) (nn.GELU() exact form, pacman_mappo_resnet.py:53), GELU'(z) = Phi(z) + z e / sqrt(2 pi).
+__device__ __forceinline__ float phi_cdf(float z, float &e)
+{
+    const float x = fabsf(z) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+    float poly = fmaf(t, 1.061405429f, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    poly *= t;
+    e = __builtin_amdgcn_exp2f(x * x * -1.4426950408889634f);
+    const float half_tail = 0.5f * poly * e;           // 0.5 erfc(|z| / sqrt 2)
+    return z >= 0.0f ? 1.0f - half_tail : half_tail;
+}
+__device__ __forceinline__ float gelu_fast(float z)
+{
+    float e;
+    return z * phi_cdf(z, e);
+}
+
+template <typename T> __device__ __forceinline__ float in_to_f(T v);
+template <> __device__ __forceinline__ float in_to_f<uint8_t>(uint8_t v) { return (float)v; }
+template <> __device__ __forceinline__ float in_to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float in_to_f<__hip_bfloat16>(__hip_bfloat16 v) { return __bfloat162float(v); }
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    // LDS operations of one wave execute in order; this only stops the compiler from moving them across the point
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// sum over the 32 lanes that share a GroupNorm group in P layout: all p (lane bits 0..3) and g & 1 (bit 4)
+__device__ __forceinline__ float group_sum(float v)
+{
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    return v;
+}
+// sum over the 16 lanes with the same g (same channels, different positions)
+__device__ __forceinline__ float pos_sum(float v)
+{
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+struct Geom {
+    int H, W, WP, HW, MP;
+};
+
+// Copies one sample's observation planes [8][H][W] into channels 0..7 of the map and clears channels 8..31 of the
+// board's cells (they hold the previous sample's activations).
+template <typename IN_T>
+__device__ __forceinline__ void load_obs(const IN_T *__restrict__ obs, char *map, const Geom &G, int lane)
+{
+    for (int i = lane; i < G.HW; i += 64) {
+        const int row = i / G.W, col = i - row * G.W;
+        const int pos = (row + 1) * G.WP + col + 1 + GUARD;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = in_to_f<IN_T>(obs[c * G.HW + i]);
+        uint4 w = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+        *reinterpret_cast<uint4 *>(map + map_off(pos, 0)) = w;
+        const uint4 z = {0, 0, 0, 0};
+#pragma unroll
+        for (int ch = 1; ch < 4; ++ch) *reinterpret_cast<uint4 *>(map + map_off(pos, ch)) = z;
+    }
+}
+
+__device__ __forceinline__ void load_frags_half(bf16x8 (&A)[2][9], const short *__restrict__ frag, int lane, int m)
+{
+#pragma unroll
+    for (int k = 0; k < 9; ++k) A[m][k] = *reinterpret_cast<const bf16x8 *>(frag + ((m * 9 + k) * 64 + lane) * 8);
+}
+
+__device__ __forceinline__ void load_frags(bf16x8 (&A)[2][9], const short *__restrict__ frag, int lane)
+{
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) A[m][k] = *reinterpret_cast<const bf16x8 *>(frag + ((m * 9 + k) * 64 + lane) * 8);
+}
+
+// One tile of the 3x3 convolution: 9 taps x 2 output halves on the map.  q0p = padded index of the lane's position + GUARD.
+__device__ __forceinline__ void conv_tile(const char *map, const bf16x8 (&A)[2][9], int q0p, int g, int WP, f32x4 &a0, f32x4 &a1)
+{
+    a0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int pos = q0p + (ky - 1) * WP + (kx - 1);
+            const bf16x8 b = *reinterpret_cast<const bf16x8 *>(map + map_off(pos, g));
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][ky * 3 + kx], b, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1][ky * 3 + kx], b, a1, 0, 0, 0);
+        }
+}
+
+// P-layout dump: 8 bytes per lane per (tile, half); a sample is NT * 2 * 512 bytes
+__device__ __forceinline__ size_t dump_index(size_t sample, int NT, int t, int m, int lane) { return ((sample * NT + t) * 2 + m) * 64 + lane; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Forward
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT, typename IN_T, bool SAVE>
+__global__ __launch_bounds__(256, 2) void pmx_actor_fwd_kernel(const IN_T *__restrict__ obs, const char *__restrict__ pack,
+                                                              uint2 *__restrict__ feat, uint2 *__restrict__ hsave,
+                                                              uint2 *__restrict__ ysave, float *__restrict__ stats,
+                                                              uint2 *__restrict__ rtmp, int B, int H, int W, float eps)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = lane & 15, g = lane >> 4;
+    Geom G;
+    G.H = H, G.W = W, G.WP = W + 2, G.HW = H * W, G.MP = map_positions(NT, W + 2);
+    char *map = smem + (size_t)wave * G.MP * 64;
+    for (int i = lane; i < G.MP * 4; i += 64) reinterpret_cast<uint4 *>(map)[i] = uint4{0, 0, 0, 0};
+    // which of the lane's NT positions are board cells
+    uint32_t vmask = 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int q = G.WP + 16 * t + p, row = q / G.WP, col = q - row * G.WP;
+        if (col >= 1 && col <= W && row <= H) vmask |= 1u << t;
+    }
+    const short *fw = reinterpret_cast<const short *>(pack + PACK_FWD);
+    const float *biasp = reinterpret_cast<const float *>(pack + PACK_BIAS);
+    const float *gnwp = reinterpret_cast<const float *>(pack + PACK_GNW);
+    const float *gnbp = reinterpret_cast<const float *>(pack + PACK_GNB);
+    const float inv_n = 1.0f / (float)(8 * G.HW);
+
+    for (int s = blockIdx.x * 4 + wave; s < B; s += gridDim.x * 4) {
+        wave_lds_fence();
+        load_obs<IN_T>(obs + (size_t)s * 8 * G.HW, map, G, lane);
+        wave_lds_fence();
+        // values that do not change from sample to sample or layer to layer (weight fragments of layer 0, masks, LDS
+        // addresses) must not be hoisted out of these loops -- there are hundreds and they would live in scratch; the empty
+        // asm statements make their inputs opaque at the point of use
+        const short *fws = fw;
+        asm volatile("" : "+s"(fws));
+        bf16x8 A[2][9];
+        load_frags(A, fws, lane);
+#pragma unroll 1
+        for (int li = 0; li < NLAYER; ++li) {
+            int l = li;
+            asm volatile("" : "+s"(l));
+            // everything below is branch-free: a layer without GroupNorm normalises with mean 0 / rstd 1 / weight 1 / bias 0
+            // (the pack holds those), a layer without the skip connection selects 0 for the residual (a select, not a
+            // product: the slot it would read may hold anything, NaNs included)
+            const bool has_gn = l >= 2;
+            const bool res_on = l >= 3 && (l & 1);
+            int WPv = G.WP, pq = p + GUARD;
+            uint32_t vmk = vmask;
+            asm volatile("" : "+s"(WPv));
+            asm volatile("" : "+v"(pq), "+v"(vmk));
+            // the activation dump of this layer and of the block input two layers back (the residual).  Training keeps every
+            // layer's dump for the backward pass; inference needs one slot per wave, for the residual only (written by
+            // layers 1, 3, 5, read back by the same lanes two layers later: L2-resident)
+            uint2 *ydst = SAVE ? ysave + dump_index((size_t)l * B + s, NT, 0, 0, lane)
+                               : rtmp + dump_index((size_t)blockIdx.x * 4 + wave, NT, 0, 0, lane);
+            const uint2 *rsrc = SAVE ? ysave + dump_index((size_t)(l >= 2 ? l - 2 : 0) * B + s, NT, 0, 0, lane) : ydst;
+            const bool write_y = SAVE || (l & 1);
+            float bias[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bias[m][r] = biasp[l * 32 + 16 * m + 4 * g + r];
+            uint2 hp[NT][2];                               // bf16-rounded convolution output (+ bias), packed
+            float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f32x4 a[2];
+                conv_tile(map, A, WPv + 16 * t + pq, g, WPv, a[0], a[1]);
+                const float vm = ((vmk >> t) & 1) ? 1.0f : 0.0f;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (a[m][r] + bias[m][r]) * vm;
+                    uint2 h2 = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+                    asm volatile("" : "+v"(h2.x), "+v"(h2.y));   // pins the pack next to its tile (else it sinks to pass 2 and
+                                                                 // all NT x 8 fp32 accumulators stay live through the layer)
+                    hp[t][m] = h2;
+                    const float h0 = lo_f(h2.x), h1 = hi_f(h2.x), h2f = lo_f(h2.y), h3 = hi_f(h2.y);
+                    s1[m] += (h0 + h1) + (h2f + h3);
+                    s2[m] += fmaf(h0, h0, h1 * h1) + fmaf(h2f, h2f, h3 * h3);
+                    if (SAVE) hsave[dump_index((size_t)l * B + s, NT, t, m, lane)] = h2;
+                }
+                __builtin_amdgcn_sched_barrier(0);         // one tile at a time: bounds the registers the scheduler spends on overlap
+            }
+            // the map has been read for the last time in this layer: the next layer's weights can start to arrive
+            load_frags(A, fws + (size_t)(l + 1 < NLAYER ? l + 1 : l) * FRAG_PER_LAYER, lane);
+            float mean[2], rstd[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const float a1 = group_sum(s1[m]) * inv_n, a2 = group_sum(s2[m]) * inv_n;
+                mean[m] = has_gn ? a1 : 0.0f;
+                rstd[m] = has_gn ? __builtin_amdgcn_rsqf(fmaxf(a2 - a1 * a1, 0.0f) + eps) : 1.0f;
+            }
+            if (SAVE && p == 0 && (g & 1) == 0) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    float *st = stats + (((size_t)l * B + s) * 4 + 2 * m + (g >> 1)) * 2;
+                    st[0] = mean[m], st[1] = rstd[m];
+                }
+            }
+            float gw[2][4], gb[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gw[m][r] = gnwp[l * 32 + 16 * m + 4 * g + r], gb[m][r] = gnbp[l * 32 + 16 * m + 4 * g + r];
+            wave_lds_fence();
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float vm = ((vmk >> t) & 1) ? 1.0f : 0.0f;
+                const int pos = WPv + 16 * t + pq;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const uint2 r2 = rsrc[(t * 2 + m) * 64];
+                    const float hv[4] = {lo_f(hp[t][m].x), hi_f(hp[t][m].x), lo_f(hp[t][m].y), hi_f(hp[t][m].y)};
+                    const uint32_t rx = res_on ? r2.x : 0u, ry = res_on ? r2.y : 0u;
+                    const float rv[4] = {lo_f(rx), hi_f(rx), lo_f(ry), hi_f(ry)};
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float z = rv[r] + fmaf((hv[r] - mean[m]) * rstd[m], gw[m][r], gb[m][r]);
+                        v[r] = gelu_fast(z) * vm;
+                    }
+                    const uint2 y2 = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+                    *reinterpret_cast<uint2 *>(map + map_off(pos, 2 * m + (g >> 1)) + (g & 1) * 8) = y2;
+                    if (write_y) ydst[(t * 2 + m) * 64] = y2;
+                    if (l == NLAYER - 1 && vm != 0.0f) {
+                        const int q = WPv + 16 * t + p, row = q / WPv, col = q - row * WPv;
+                        feat[((size_t)s * G.HW + (row - 1) * W + (col - 1)) * 8 + 4 * m + g] = y2;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            wave_lds_fence();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward, data path: one wave owns a sample from the last layer back to the first, mirroring the forward kernel.  The
+// gradient travels from layer to layer in REGISTERS (P layout, packed bf16 -- the rounding autograd applies to a bf16
+// tensor), the skip-connection gradient of a block as well; per layer the kernel reads the saved pre-activation (and the
+// skip input), writes dH -- the gradient of the convolution output -- to its LDS map for the input-gradient convolution
+// (same loop as forward, flipped weights), and dumps dH to global memory in the OPERAND layout the weight-gradient kernel
+// wants (transposed through ds_read_b64_tr_b16: A[co][k = position]), so that kernel needs no map for it.  The bias and
+// GroupNorm-affine gradients are summed per wave in LDS over all its samples and added to global memory once at the end.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256, 2) void pmx_actor_bwd_data_kernel(const char *__restrict__ pack, const uint2 *__restrict__ dfeat,
+                                                                   const uint2 *__restrict__ hsave, const uint2 *__restrict__ ysave,
+                                                                   const float *__restrict__ stats, bf16x8 *__restrict__ dasave,
+                                                                   uint2 *__restrict__ sktmp, float *__restrict__ grad, int B, int H,
+                                                                   int W)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = lane & 15, g = lane >> 4;
+    Geom G;
+    G.H = H, G.W = W, G.WP = W + 2, G.HW = H * W, G.MP = map_positions(NT, W + 2);
+    constexpr int KS = (NT + 1) / 2;
+    constexpr int TG = 4;                                     // tiles per group of global loads (issued together, used behind)
+    char *map = smem + (size_t)wave * (G.MP * 64 + NLAYER * 96 * 4);
+    float *acc = reinterpret_cast<float *>(map + (size_t)G.MP * 64);       // [8 layers][bias 32 | gn weight 32 | gn bias 32]
+    for (int i = lane; i < G.MP * 4; i += 64) reinterpret_cast<uint4 *>(map)[i] = uint4{0, 0, 0, 0};
+    for (int i = lane; i < NLAYER * 96; i += 64) acc[i] = 0.0f;
+    uint32_t vmask = 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int q = G.WP + 16 * t + p, row = q / G.WP, col = q - row * G.WP;
+        if (col >= 1 && col <= W && row <= H) vmask |= 1u << t;
+    }
+    const short *bw = reinterpret_cast<const short *>(pack + PACK_BWD);
+    const float *gnwp = reinterpret_cast<const float *>(pack + PACK_GNW);
+    const float *gnbp = reinterpret_cast<const float *>(pack + PACK_GNB);
+    const float inv_n = 1.0f / (float)(8 * G.HW);
+    const int tr_row = (lane & 15) >> 2, tr_pc = lane & 3;     // transposing reads: lane 4*row + pc of a 16-lane group
+    bool any = false;
+
+    for (int s = blockIdx.x * 4 + wave; s < B; s += gridDim.x * 4) {
+        any = true;
+        uint2 dv[NT][2];                                       // dY of the current layer, then its dz, then the next dY
+        // the gradient arriving over a block's skip connection waits in a per-wave global slot (L2-resident, same lanes
+        // write and read) from the block's second convolution to its first: 44 registers the passes below need
+        uint2 *skp = sktmp + dump_index((size_t)blockIdx.x * 4 + wave, NT, 0, 0, lane);
+        {
+            int WPo = G.WP;
+            asm volatile("" : "+s"(WPo));
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int q = WPo + 16 * t + p, row = q / WPo, col = q - row * WPo;
+                const bool valid = (vmask >> t) & 1;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    dv[t][m] = uint2{0, 0};
+                    if (valid) dv[t][m] = dfeat[((size_t)s * G.HW + (row - 1) * W + (col - 1)) * 8 + 4 * m + g];
+                }
+            }
+        }
+#pragma unroll 1
+        for (int li = NLAYER - 1; li >= 0; --li) {
+            int l = li;
+            asm volatile("" : "+s"(l));
+            const bool has_gn = l >= 2, has_res = l >= 3 && (l & 1), adds_skip = l >= 2 && !(l & 1);
+            const float gn_on = has_gn ? 1.0f : 0.0f;
+            const int lres = l >= 2 ? l - 2 : 0;
+            int WPv = G.WP, pq = p + GUARD;
+            uint32_t vmk = vmask;
+            asm volatile("" : "+s"(WPv));
+            asm volatile("" : "+v"(pq), "+v"(vmk));
+            float gw[2][4], gb[2][4], mean[2], rstd[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gw[m][r] = gnwp[l * 32 + 16 * m + 4 * g + r], gb[m][r] = gnbp[l * 32 + 16 * m + 4 * g + r];
+                const float *st = stats + (((size_t)l * B + s) * 4 + 2 * m + (g >> 1)) * 2;
+                mean[m] = st[0], rstd[m] = st[1];                  // (0, 1) for the layers without GroupNorm
+            }
+            // ---- pass 1: dz = dY GELU'(z), sums for the GroupNorm backward and for the affine gradients -----------------
+            uint2 hp[NT][2];
+            float S1[2] = {0.f, 0.f}, S2[2] = {0.f, 0.f};
+            float dgw[2][4], dgb[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dgw[m][r] = dgb[m][r] = 0.0f;
+#pragma unroll
+            for (int t0 = 0; t0 < NT; t0 += TG) {
+                uint2 xg[TG][2];
+#pragma unroll
+                for (int tt = 0; tt < TG; ++tt)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        if (t0 + tt < NT) {
+                            hp[t0 + tt][m] = hsave[dump_index((size_t)l * B + s, NT, t0 + tt, m, lane)];
+                            xg[tt][m] = ysave[dump_index((size_t)lres * B + s, NT, t0 + tt, m, lane)];
+                        }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tt = 0; tt < TG; ++tt)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        if (t0 + tt < NT) {
+                            const int t = t0 + tt;
+                            const uint2 dy = dv[t][m], h2 = hp[t][m], x2 = xg[tt][m];
+                            const float hv[4] = {lo_f(h2.x), hi_f(h2.x), lo_f(h2.y), hi_f(h2.y)};
+                            const uint32_t xx = has_res ? x2.x : 0u, xy = has_res ? x2.y : 0u;
+                            const float xv[4] = {lo_f(xx), hi_f(xx), lo_f(xy), hi_f(xy)};
+                            const float d[4] = {lo_f(dy.x), hi_f(dy.x), lo_f(dy.y), hi_f(dy.y)};
+                            float dzf[4], xh[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                xh[r] = (hv[r] - mean[m]) * rstd[m];
+                                const float z = xv[r] + fmaf(xh[r], gw[m][r], gb[m][r]);
+                                float e;
+                                const float phi = phi_cdf(z, e);
+                                dzf[r] = d[r] * fmaf(z * 0.3989422804014327f, e, phi);
+                            }
+                            uint2 dzq = {pack2(dzf[0], dzf[1]), pack2(dzf[2], dzf[3])};
+                            asm volatile("" : "+v"(dzq.x), "+v"(dzq.y));
+                            dv[t][m] = dzq;
+                            const float dzr[4] = {lo_f(dzq.x), hi_f(dzq.x), lo_f(dzq.y), hi_f(dzq.y)};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                dgb[m][r] += dzr[r];
+                                dgw[m][r] = fmaf(dzr[r], xh[r], dgw[m][r]);
+                                const float gd = gw[m][r] * dzr[r];
+                                S1[m] += gd;
+                                S2[m] = fmaf(gd, xh[r], S2[m]);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+            }
+            if (has_res) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) skp[(t * 2 + m) * 64] = dv[t][m];
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) S1[m] = group_sum(S1[m]) * inv_n * gn_on, S2[m] = group_sum(S2[m]) * inv_n * gn_on;
+            wave_lds_fence();
+            // ---- pass 2: dh, into the map (for the input gradient) ---------------------------------------------------------
+            float dbias[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dbias[m][r] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float vm = ((vmk >> t) & 1) ? 1.0f : 0.0f;
+                const int pos = WPv + 16 * t + pq;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const uint2 h2 = hp[t][m];
+                    const float hv[4] = {lo_f(h2.x), hi_f(h2.x), lo_f(h2.y), hi_f(h2.y)};
+                    const float dzr[4] = {lo_f(dv[t][m].x), hi_f(dv[t][m].x), lo_f(dv[t][m].y), hi_f(dv[t][m].y)};
+                    float dh[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xh = (hv[r] - mean[m]) * rstd[m];
+                        dh[r] = vm * rstd[m] * (gw[m][r] * dzr[r] - S1[m] - xh * S2[m]);
+                    }
+                    const uint2 d2 = {pack2(dh[0], dh[1]), pack2(dh[2], dh[3])};
+                    // the bias gradient sums what the matrix cores see (the bf16-rounded dh), like autograd on a bf16 tensor
+                    dbias[m][0] += lo_f(d2.x), dbias[m][1] += hi_f(d2.x), dbias[m][2] += lo_f(d2.y), dbias[m][3] += hi_f(d2.y);
+                    *reinterpret_cast<uint2 *>(map + map_off(pos, 2 * m + (g >> 1)) + (g & 1) * 8) = d2;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // per-channel sums over the sample's positions -> the wave's LDS accumulators (lanes p == 0 own 4 channels each)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float b = pos_sum(dbias[m][r]), w = pos_sum(dgw[m][r]), c = pos_sum(dgb[m][r]);
+                    if (p == 0) {
+                        float *a3 = acc + l * 96 + 16 * m + 4 * g + r;
+                        a3[0] += b, a3[32] += w, a3[64] += c;
+                    }
+                }
+            wave_lds_fence();
+            // ---- dH in the weight-gradient kernel's operand layout: A[co][k = position], transposed out of the map --------
+            {
+                bf16x8 *dst = dasave + (((size_t)l * B + s) * KS * 2) * 64 + lane;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int qk = WPv + 32 * ks + 8 * g + tr_row + GUARD;
+#pragma unroll
+                    for (int mo = 0; mo < 2; ++mo) {
+                        const int o0 = map_off(qk, 2 * mo + (tr_pc >> 1)) + (tr_pc & 1) * 8;
+                        const int o1 = map_off(qk + 4, 2 * mo + (tr_pc >> 1)) + (tr_pc & 1) * 8;
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)(map + o0));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)(map + o1));
+                        dst[(ks * 2 + mo) * 64] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
+                }
+            }
+            // ---- input gradient: the same convolution with flipped, transposed weights; it is the next layer's dY ----------
+            if (l > 0) {
+                const short *bws = bw + (size_t)l * FRAG_PER_LAYER;
+                asm volatile("" : "+s"(bws));
+                bf16x8 A[2][9];
+                load_frags(A, bws, lane);
+                uint2 skip[NT][2];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) skip[t][m] = skp[(t * 2 + m) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    f32x4 a[2];
+                    conv_tile(map, A, WPv + 16 * t + pq, g, WPv, a[0], a[1]);
+                    const float vm = ((vmk >> t) & 1) ? 1.0f : 0.0f;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const uint32_t sx = adds_skip ? skip[t][m].x : 0u, sy = adds_skip ? skip[t][m].y : 0u;
+                        const float v0 = (lo_f(sx) + a[m][0]) * vm, v1 = (hi_f(sx) + a[m][1]) * vm;
+                        const float v2 = (lo_f(sy) + a[m][2]) * vm, v3 = (hi_f(sy) + a[m][3]) * vm;
+                        uint2 nx = {pack2(v0, v1), pack2(v2, v3)};
+                        asm volatile("" : "+v"(nx.x), "+v"(nx.y));
+                        dv[t][m] = nx;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            wave_lds_fence();
+        }
+    }
+    if (any) {
+        wave_lds_fence();
+        for (int i = lane; i < NLAYER * 96; i += 64) {
+            const int l = i / 96, j = i - l * 96, kind = j >> 5, ch = j & 31;
+            const float v = acc[i];
+            if (v != 0.0f) atomicAdd(grad + (kind == 0 ? GRAD_B : kind == 1 ? GRAD_GNW : GRAD_GNB) + l * 32 + ch, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward, weight gradient: dW[co][ci][tap] = sum over samples and positions of dH[pos][co] X[pos + shift(tap)][ci], a
+// contraction over POSITIONS.  blockIdx.y = layer, blockIdx.x = chunk of samples; a wave keeps the layer's 36 output tiles
+// (2 co-halves x 2 ci-halves x 9 taps, 144 accumulator registers) across its samples.  Per sample: the A operands
+// (dH, already in operand layout) come straight from global memory, the layer's input activation goes into the wave's LDS
+// map once and is read back tap by tap through the transposing read.  One block-level sum through LDS and one float
+// atomic per value at the end.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT, typename IN_T>
+__global__ __launch_bounds__(256, 2) void pmx_actor_bwd_weight_kernel(const IN_T *__restrict__ obs, const uint2 *__restrict__ ysave,
+                                                                     const bf16x8 *__restrict__ dasave, float *__restrict__ grad,
+                                                                     int B, int H, int W, int per_wave)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = lane & 15, g = lane >> 4;
+    const int l = blockIdx.y;
+    Geom G;
+    G.H = H, G.W = W, G.WP = W + 2, G.HW = H * W, G.MP = map_positions(NT, W + 2);
+    constexpr int KS = (NT + 1) / 2;
+    char *mapB = smem + (size_t)wave * G.MP * 64;
+    for (int i = lane; i < G.MP * 4; i += 64) reinterpret_cast<uint4 *>(mapB)[i] = uint4{0, 0, 0, 0};
+    const int tr_row = (lane & 15) >> 2, tr_pc = lane & 3;
+    f32x4 accw[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) accw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int s_begin = (blockIdx.x * 4 + wave) * per_wave;
+    const int s_end = s_begin + per_wave < B ? s_begin + per_wave : B;
+    for (int s = s_begin; s < s_end; ++s) {
+        int WPv = G.WP, pq = p + GUARD;
+        asm volatile("" : "+s"(WPv));
+        asm volatile("" : "+v"(pq));
+        wave_lds_fence();
+        if (l == 0) {
+            load_obs<IN_T>(obs + (size_t)s * 8 * G.HW, mapB, G, lane);
+        } else {
+            uint2 xin[NT][2];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) xin[t][m] = ysave[dump_index((size_t)(l - 1) * B + s, NT, t, m, lane)];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    *reinterpret_cast<uint2 *>(mapB + map_off(WPv + 16 * t + pq, 2 * m + (g >> 1)) + (g & 1) * 8) = xin[t][m];
+        }
+        wave_lds_fence();
+        const bf16x8 *asrc = dasave + (((size_t)l * B + s) * KS * 2) * 64 + lane;
+#pragma unroll 1
+        for (int ks = 0; ks < KS; ++ks) {
+            const int qk = WPv + 32 * ks + 8 * g + tr_row + GUARD;
+            const bf16x8 Ad0 = asrc[(ks * 2 + 0) * 64], Ad1 = asrc[(ks * 2 + 1) * 64];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int qx = qk + (ky - 1) * WPv + (kx - 1);
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        const int o0 = map_off(qx, 2 * ni + (tr_pc >> 1)) + (tr_pc & 1) * 8;
+                        const int o1 = map_off(qx + 4, 2 * ni + (tr_pc >> 1)) + (tr_pc & 1) * 8;
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)(mapB + o0));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)(mapB + o1));
+                        const bf16x8 Bx = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        accw[(0 * 2 + ni) * 9 + ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ad0, Bx, accw[(0 * 2 + ni) * 9 + ky * 3 + kx], 0, 0, 0);
+                        accw[(1 * 2 + ni) * 9 + ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ad1, Bx, accw[(1 * 2 + ni) * 9 + ky * 3 + kx], 0, 0, 0);
+                    }
+                }
+        }
+    }
+    // block-level sum through LDS (the maps are free now), then one atomic add per value
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem);
+    constexpr int PER_ROUND = 9;                              // 4 waves x 9 tiles x 1 KB = 36 KB of scratch per round
+#pragma unroll
+    for (int round = 0; round < 4; ++round) {
+#pragma unroll
+        for (int i = 0; i < PER_ROUND; ++i)
+            *reinterpret_cast<f32x4 *>(red + ((size_t)(wave * PER_ROUND + i) * 64 + lane) * 4) = accw[round * PER_ROUND + i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < PER_ROUND * 64; i += 256) {
+            f32x4 v = *reinterpret_cast<const f32x4 *>(red + (size_t)i * 4);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const f32x4 u = *reinterpret_cast<const f32x4 *>(red + ((size_t)w * PER_ROUND * 64 + i) * 4);
+                v[0] += u[0], v[1] += u[1], v[2] += u[2], v[3] += u[3];
+            }
+            float *dst = grad + GRAD_W + ((size_t)l * 36 + round * PER_ROUND) * 256 + (size_t)i * 4;
+            if (v[0] != 0.f) atomicAdd(dst + 0, v[0]);
+            if (v[1] != 0.f) atomicAdd(dst + 1, v[1]);
+            if (v[2] != 0.f) atomicAdd(dst + 2, v[2]);
+            if (v[3] != 0.f) atomicAdd(dst + 3, v[3]);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Parameter packing: fp32 [cout][cin][3][3] weights -> bf16 MFMA A fragments (forward and input-gradient order)
+// ---------------------------------------------------------------------------------------------------------------
+struct PackArgs {
+    const float *w[NLAYER], *b[NLAYER], *gw[NLAYER], *gb[NLAYER];
+    int cin[NLAYER], cout[NLAYER];
+};
+
+__global__ __launch_bounds__(256) void pmx_actor_pack_kernel(PackArgs a, char *__restrict__ pack)
+{
+    const int l = blockIdx.y;
+    short *fw = reinterpret_cast<short *>(pack + PACK_FWD) + (size_t)l * FRAG_PER_LAYER;
+    short *bw = reinterpret_cast<short *>(pack + PACK_BWD) + (size_t)l * FRAG_PER_LAYER;
+    const int cin = a.cin[l], cout = a.cout[l];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < FRAG_PER_LAYER; i += gridDim.x * 256) {
+        const int j = i & 7, lane = (i >> 3) & 63, k = (i >> 9) % 9, m = i / (512 * 9);
+        const int row = 16 * m + (lane & 15), kk = 8 * (lane >> 4) + j;       // A[row][kk] of tap k
+        // forward: row = output channel, kk = input channel
+        float vf = 0.f, vb = 0.f;
+        if (row < cout && kk < cin) vf = a.w[l][((size_t)row * cin + kk) * 9 + k];
+        // input gradient: row = input channel, kk = output channel, tap flipped
+        if (row < cin && kk < cout) vb = a.w[l][((size_t)kk * cin + row) * 9 + (8 - k)];
+        fw[i] = (short)(pack2(vf, 0.f) & 0xFFFF);
+        bw[i] = (short)(pack2(vb, 0.f) & 0xFFFF);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 32) {
+        const int c = threadIdx.x;
+        reinterpret_cast<float *>(pack + PACK_BIAS)[l * 32 + c] = c < cout ? a.b[l][c] : 0.f;
+        reinterpret_cast<float *>(pack + PACK_GNW)[l * 32 + c] = a.gw[l] ? a.gw[l][c] : 1.f;
+        reinterpret_cast<float *>(pack + PACK_GNB)[l * 32 + c] = a.gb[l] ? a.gb[l][c] : 0.f;
+    }
+}
+
+struct UnpackArgs {
+    float *w[NLAYER], *b[NLAYER], *gw[NLAYER], *gb[NLAYER];
+    int cin[NLAYER], cout[NLAYER];
+};
+
+// gradient tiles (D layout: row = co = 4g + r, col = ci = p) -> the parameters' own shapes
+__global__ __launch_bounds__(256) void pmx_actor_unpack_kernel(UnpackArgs a, const float *__restrict__ grad)
+{
+    const int l = blockIdx.y;
+    const int cin = a.cin[l], cout = a.cout[l];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 36 * 256; i += gridDim.x * 256) {
+        const int r = i & 3, lane = (i >> 2) & 63, tile = i >> 8;
+        const int k = tile % 9, ni = (tile / 9) & 1, mo = tile / 18;
+        const int co = 16 * mo + 4 * (lane >> 4) + r, ci = 16 * ni + (lane & 15);
+        if (co < cout && ci < cin) a.w[l][((size_t)co * cin + ci) * 9 + k] = grad[GRAD_W + (size_t)l * 36 * 256 + i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 32) {
+        const int c = threadIdx.x;
+        if (c < cout) a.b[l][c] = grad[GRAD_B + l * 32 + c];
+        if (a.gw[l]) a.gw[l][c] = grad[GRAD_GNW + l * 32 + c];
+        if (a.gb[l]) a.gb[l][c] = grad[GRAD_GNB + l * 32 + c];
+    }
+}
+
+int tiles_for(int H, int W) { return (H * (W + 2) + 15) / 16; }
+
+thread_local char g_err[256];
+
+}   // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------
+static const int kCin[NLAYER] = {8, 16, 32, 32, 32, 32, 32, 32};
+static const int kCout[NLAYER] = {16, 32, 32, 32, 32, 32, 32, 32};
+
+extern "C" int pmx_actor_supported(int32_t H, int32_t W)
+{
+    if (H < 1 || W < 1 || H > PMX_MAX_DIM || W > PMX_MAX_DIM) return 0;
+    const int nt = tiles_for(H, W);
+    return nt == 10 || nt == 11;
+}
+
+extern "C" int pmx_actor_sizes(int32_t H, int32_t W, int64_t B, int64_t *save_bytes, int64_t *scratch_bytes)
+{
+    if (!pmx_actor_supported(H, W) || B < 0) return PMX_ERR_UNSUPPORTED;
+    const int64_t dump = (int64_t)tiles_for(H, W) * 1024;            // one P-layout dump of one sample
+    if (save_bytes) *save_bytes = B * (8 * dump + 8 * dump + 8 * 4 * 2 * 4);
+    if (scratch_bytes) {
+        const int64_t infer = 2048 * dump;                                     // inference: one skip-input slot per resident wave
+        const int64_t bwd = B * 8 * (int64_t)((tiles_for(H, W) + 1) / 2) * 2048 + infer; // backward: dH operand fragments of the 8 layers + skip slots
+        *scratch_bytes = infer > bwd ? infer : bwd;
+    }
+    return PMX_OK;
+}
+
+extern "C" int pmx_actor_pack(const pmx_actor_params *p, void *pack_dev, void *stream)
+{
+    if (!p || !pack_dev) return PMX_ERR_INVALID;
+    PackArgs a;
+    for (int l = 0; l < NLAYER; ++l) {
+        a.w[l] = p->conv_w[l], a.b[l] = p->conv_b[l];
+        a.gw[l] = l >= 2 ? p->gn_w[l - 2] : nullptr, a.gb[l] = l >= 2 ? p->gn_b[l - 2] : nullptr;
+        a.cin[l] = kCin[l], a.cout[l] = kCout[l];
+        if (!a.w[l] || !a.b[l] || (l >= 2 && (!a.gw[l] || !a.gb[l]))) return PMX_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(pmx_actor_pack_kernel, dim3(9, NLAYER), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a,
+                       reinterpret_cast<char *>(pack_dev));
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
+
+extern "C" int pmx_actor_unpack_grads(const float *grad_dev, const pmx_actor_params *out, void *stream)
+{
+    if (!grad_dev || !out) return PMX_ERR_INVALID;
+    UnpackArgs a;
+    for (int l = 0; l < NLAYER; ++l) {
+        a.w[l] = const_cast<float *>(out->conv_w[l]), a.b[l] = const_cast<float *>(out->conv_b[l]);
+        a.gw[l] = l >= 2 ? const_cast<float *>(out->gn_w[l - 2]) : nullptr;
+        a.gb[l] = l >= 2 ? const_cast<float *>(out->gn_b[l - 2]) : nullptr;
+        a.cin[l] = kCin[l], a.cout[l] = kCout[l];
+        if (!a.w[l] || !a.b[l] || (l >= 2 && (!a.gw[l] || !a.gb[l]))) return PMX_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(pmx_actor_unpack_kernel, dim3(9, NLAYER), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, grad_dev);
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
+
+namespace {
+
+template <typename K> int allow_lds(K kernel, size_t lds)
+{
+    // per device: the attribute belongs to the function on the CURRENT device
+    static bool done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PMX_ERR_HIP;
+    if (lds > 65536 && !done[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return PMX_ERR_HIP;
+        done[dev] = true;
+    }
+    return PMX_OK;
+}
+
+int grid_for(int64_t B, int blocks_per_cu)
+{
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    const int64_t want = (B + 3) / 4;
+    const int64_t cap = (int64_t)cus * blocks_per_cu;
+    return (int)(want < cap ? want : cap);
+}
+
+template <int NT, typename IN_T>
+int launch_fwd(const void *obs, const void *pack, void *feat, void *save, void *scratch, int64_t B, int H, int W, hipStream_t st)
+{
+    const size_t lds = (size_t)4 * map_positions(NT, W + 2) * 64;
+    const int64_t dump = (int64_t)NT * 128;                                 // uint2 elements of one dump
+    uint2 *hs = reinterpret_cast<uint2 *>(save), *ys = hs ? hs + 8 * B * dump : nullptr;
+    float *stt = hs ? reinterpret_cast<float *>(ys + 8 * B * dump) : nullptr;
+    uint2 *rtmp = reinterpret_cast<uint2 *>(scratch);
+    if (!save && !rtmp) return PMX_ERR_INVALID;
+    if (save) {
+        int rc = allow_lds(pmx_actor_fwd_kernel<NT, IN_T, true>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((pmx_actor_fwd_kernel<NT, IN_T, true>), dim3(grid_for(B, 2)), dim3(256), lds, st, (const IN_T *)obs,
+                           (const char *)pack, (uint2 *)feat, hs, ys, stt, rtmp, (int)B, H, W, 1e-5f);
+    } else {
+        int rc = allow_lds(pmx_actor_fwd_kernel<NT, IN_T, false>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((pmx_actor_fwd_kernel<NT, IN_T, false>), dim3(grid_for(B, 2)), dim3(256), lds, st, (const IN_T *)obs,
+                           (const char *)pack, (uint2 *)feat, hs, ys, stt, rtmp, (int)B, H, W, 1e-5f);
+    }
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
+
+template <int NT, typename IN_T>
+int launch_bwd(const void *obs, const void *pack, const void *save, const void *dfeat, void *scratch, float *grad, int64_t B,
+               int H, int W, hipStream_t st)
+{
+    const int mp = map_positions(NT, W + 2);
+    constexpr int KS = (NT + 1) / 2;
+    const int64_t dump = (int64_t)NT * 128;
+    const uint2 *hs = reinterpret_cast<const uint2 *>(save), *ys = hs + 8 * B * dump;
+    const float *stt = reinterpret_cast<const float *>(ys + 8 * B * dump);
+    bf16x8 *da = reinterpret_cast<bf16x8 *>(scratch);                       // [8][B][KS * 2][64] operand fragments of dH
+    uint2 *sk = reinterpret_cast<uint2 *>(da + (size_t)8 * B * KS * 2 * 64);  // then one skip-gradient slot per resident wave
+    const size_t lds_d = (size_t)4 * (mp * 64 + NLAYER * 96 * 4);
+    int rc = allow_lds(pmx_actor_bwd_data_kernel<NT>, lds_d);
+    if (rc) return rc;
+    hipLaunchKernelGGL((pmx_actor_bwd_data_kernel<NT>), dim3(grid_for(B, 2)), dim3(256), lds_d, st, (const char *)pack, (const uint2 *)dfeat,
+                       hs, ys, stt, da, sk, grad, (int)B, H, W);
+    if (hipGetLastError() != hipSuccess) return PMX_ERR_HIP;
+    // weight gradient: layers x sample chunks; about two blocks per CU in total, each wave at least a few samples
+    const size_t lds_w = (size_t)4 * mp * 64;
+    if (lds_w < (size_t)4 * 9 * 64 * 16) return PMX_ERR_UNSUPPORTED;           // the reduction scratch must fit in the maps
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    int64_t chunks = (2 * cus) / NLAYER;
+    int64_t per_wave = (B + chunks * 4 - 1) / (chunks * 4);
+    if (per_wave < 2) per_wave = 2;
+    chunks = (B + per_wave * 4 - 1) / (per_wave * 4);
+    rc = allow_lds(pmx_actor_bwd_weight_kernel<NT, IN_T>, lds_w);
+    if (rc) return rc;
+    hipLaunchKernelGGL((pmx_actor_bwd_weight_kernel<NT, IN_T>), dim3((unsigned)chunks, NLAYER), dim3(256), lds_w, st, (const IN_T *)obs, ys,
+                       (const bf16x8 *)da, grad, (int)B, H, W, (int)per_wave);
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
+
+}   // namespace
+
+extern "C" int pmx_actor_forward(const void *obs_dev, int32_t obs_dtype, const void *pack_dev, void *feat_dev, void *save_dev,
+                                 void *scratch_dev, int64_t B, int32_t H, int32_t W, void *stream)
+{
+    if (B == 0) return pmx_actor_supported(H, W) ? PMX_OK : PMX_ERR_UNSUPPORTED;      // nothing to do (pointers may be null)
+    if (!obs_dev || !pack_dev || !feat_dev || B < 0) return PMX_ERR_INVALID;
+    if (!pmx_actor_supported(H, W)) return PMX_ERR_UNSUPPORTED;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int nt = tiles_for(H, W);
+#ifdef PMX_ACTOR_EXP      /* compile-time experiments: one instantiation only */
+#define PMX_FWD(NT) return launch_fwd<11, __hip_bfloat16>(obs_dev, pack_dev, feat_dev, save_dev, scratch_dev, B, H, W, st);
+#else
+#define PMX_FWD(NT)                                                                                                      \
+    switch (obs_dtype) {                                                                                                 \
+    case PMX_OBS_F32: return launch_fwd<NT, float>(obs_dev, pack_dev, feat_dev, save_dev, scratch_dev, B, H, W, st);                  \
+    case PMX_OBS_BF16: return launch_fwd<NT, __hip_bfloat16>(obs_dev, pack_dev, feat_dev, save_dev, scratch_dev, B, H, W, st);        \
+    case PMX_OBS_U8: return launch_fwd<NT, uint8_t>(obs_dev, pack_dev, feat_dev, save_dev, scratch_dev, B, H, W, st);                 \
+    default: return PMX_ERR_INVALID;                                                                                     \
+    }
+#endif
+    if (nt == 10) { PMX_FWD(10) }
+    PMX_FWD(11)
+#undef PMX_FWD
+}
+
+extern "C" int pmx_actor_backward(const void *obs_dev, int32_t obs_dtype, const void *pack_dev, const void *save_dev,
+                                  const void *dfeat_dev, void *scratch_dev, float *grad_dev, int64_t B, int32_t H, int32_t W,
+                                  void *stream)
+{
+    if (!obs_dev || !pack_dev || !save_dev || !dfeat_dev || !scratch_dev || !grad_dev || B < 0) return PMX_ERR_INVALID;
+    if (!pmx_actor_supported(H, W)) return PMX_ERR_UNSUPPORTED;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(grad_dev, 0, sizeof(float) * GRAD_FLOATS, st) != hipSuccess) return PMX_ERR_HIP;
+    if (B == 0) return PMX_OK;
+    const int nt = tiles_for(H, W);
+#ifdef PMX_ACTOR_EXP
+#define PMX_BWD(NT) return launch_bwd<11, __hip_bfloat16>(obs_dev, pack_dev, save_dev, dfeat_dev, scratch_dev, grad_dev, B, H, W, st);
+#else
+#define PMX_BWD(NT)                                                                                                                  \
+    switch (obs_dtype) {                                                                                                             \
+    case PMX_OBS_F32: return launch_bwd<NT, float>(obs_dev, pack_dev, save_dev, dfeat_dev, scratch_dev, grad_dev, B, H, W, st);      \
+    case PMX_OBS_BF16: return launch_bwd<NT, __hip_bfloat16>(obs_dev, pack_dev, save_dev, dfeat_dev, scratch_dev, grad_dev, B, H, W, st); \
+    case PMX_OBS_U8: return launch_bwd<NT, uint8_t>(obs_dev, pack_dev, save_dev, dfeat_dev, scratch_dev, grad_dev, B, H, W, st);     \
+    default: return PMX_ERR_INVALID;                                                                                                 \
+    }
+#endif
+    if (nt == 10) { PMX_BWD(10) }
+    PMX_BWD(11)
+#undef PMX_BWD
+}

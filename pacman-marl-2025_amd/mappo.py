@@ -338,7 +338,23 @@ class MAPPOAgent(nn.Module):
             if m.bias is not None:
                 m.bias.data.fill_(0.0)
 
+    fused_tower = True      # use the fused actor-tower kernels where they apply (bf16 on the GPU, supported board size)
+
+    def _use_fused_tower(self, obs):
+        if not (self.fused_tower and obs.is_cuda and obs.dim() == 4 and obs.dtype in (torch.bfloat16, torch.uint8)):
+            return False
+        if self.actor_backbone[0].weight.dtype != torch.float32:
+            return False
+        from . import actor_tower
+        return actor_tower.tower_supported(obs.shape[2], obs.shape[3])
+
     def logits(self, obs):
+        if self._use_fused_tower(obs):
+            # one kernel for the whole convolutional tower (csrc/pmx_actor.hip); its output is channels-last, nn.Flatten's
+            # order is channel-major
+            from . import actor_tower
+            feat = actor_tower.actor_tower(self.actor_backbone, obs)             # [B, H*W, 32] bf16
+            return self.actor_head(feat.permute(0, 2, 1).reshape(feat.shape[0], -1))
         if obs.is_cuda and obs.dtype == torch.bfloat16 and obs.dim() == 4:
             # channels-last end to end: MIOpen's NHWC bf16 implicit-GEMM convolutions and the NHWC GroupNorm kernels then
             # need no layout transposes; nn.Flatten still flattens in logical (C, H, W) order, one copy at the end
