@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void pmx_actor_fwd_kernel(const IN_T *__res
 // GroupNorm-affine gradients are summed per wave in LDS over all its samples and added to global memory once at the end.
 // ---------------------------------------------------------------------------------------------------------------
 template <int NT>
-__global__ __launch_bounds__(256, 2) void pmx_actor_bwd_data_kernel(const char *__restrict__ pack, const uint2 *__restrict__ dfeat,
+__global__ __launch_bounds__(256, 1) void pmx_actor_bwd_data_kernel(const char *__restrict__ pack, const uint2 *__restrict__ dfeat,
                                                                    const uint2 *__restrict__ hsave, const uint2 *__restrict__ ysave,
                                                                    const float *__restrict__ stats, bf16x8 *__restrict__ dasave,
                                                                    uint2 *__restrict__ sktmp, float *__restrict__ grad, int B, int H,
