@@ -102,16 +102,16 @@ def cpu_baseline(layout_rows, length, seconds=12.0, layname=None):
                       f"({dt:.1f} s on 1 of {os.cpu_count()} host cores)"}
 
 
-def ppo_probe(layname, dev, rank=0, world=1, dist=None):
-    """The second half of BASELINE.json's metric, measured briefly: MAPPO rollout (env tick + policy inference + shaping)
-    and PPO optimizer steps at the reference's minibatch of 512 samples PER GPU (pacman_mappo_resnet.py:18), bf16 autocast.
-    With more than one rank every optimizer step all-reduces the flat fp32 gradient bucket over RCCL; times are
-    bracketed by barriers and the maximum over ranks is reported, rates are whole-job."""
+def e2e_probe(layname, dev, rank, world, dist, n_envs, horizon, minibatch, use_graph):
+    """One full MAPPO update -- rollout of `horizon` ticks of `n_envs` envs with policy inference, GAE, UPDATE_EPOCHS epochs of
+    `minibatch`-sample optimizer steps -- timed end to end after a short warm-up (pacman_mappo_resnet.py:461-600).  With more
+    than one rank every optimizer step all-reduces the flat fp32 gradient bucket over RCCL; the times are
+    bracketed by barriers, the maximum over ranks is reported and the rates are whole-job."""
     from pmx import trainer
-    n_envs, horizon, mb, steps = 4096, 8, 512, 40
     force_pg = dist is not None and (world > 1 or os.environ.get("PMX_BENCH_FORCE_DP") == "1")
-    tr = trainer.VecMAPPOTrainer(layname, n_envs, horizon=horizon, minibatch=mb, obs_dtype="bfloat16", device=dev, opponent="random",
-                                 rank=rank, world_size=world, process_group=dist.group.WORLD if force_pg else None)
+    tr = trainer.VecMAPPOTrainer(layname, n_envs, horizon=horizon, minibatch=minibatch, device=dev, opponent="random", rank=rank,
+                                 world_size=world, process_group=dist.group.WORLD if force_pg else None,
+                                 use_graph=use_graph and not force_pg)
     if force_pg and world == 1:
         tr.learner.world_size = 2          # rehearsal on a one-GPU box: issue the RCCL all-reduce although there is one rank
         tr.learner.pg = dist.group.WORLD
@@ -129,61 +129,56 @@ def ppo_probe(layname, dev, rank=0, world=1, dist=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    tr.rollout(); tr.compute_gae()                       # warm-up: MIOpen solver search, allocator
+    tr.rollout(); tr.compute_gae(); tr.update(max_steps=8)      # warm-up: allocator, library solver search, graph capture
+    tr.update_idx = 0
     fence()
     t0 = time.perf_counter()
-    tr.rollout(); tr.compute_gae()
+    tr.rollout()
     fence()
-    t_roll = tmax(time.perf_counter() - t0)
-    S = tr.T * tr.N * 2
-    obs = tr.obs_buf.view((S,) + tr.obs_shape)
-    merged = tr.merged_buf.view((tr.T * tr.N,) + tr.obs_shape)
-    pperm = torch.randperm(S // 2, device=dev)          # minibatches of env-tick pairs, as the trainer draws them (paired_minibatches)
-
-    def batch(k):
-        pr = pperm[k * (mb // 2):(k + 1) * (mb // 2)]
-        i = torch.stack((2 * pr, 2 * pr + 1), dim=1).reshape(-1)
-        return (tr._net_in(obs[i]), tr._net_in(merged[pr]), tr.act_buf.view(S)[i], tr.logp_buf.view(S)[i],
-                tr.adv_buf.view(S)[i], tr.ret_buf.view(S)[i])
-
-    def step(k):
-        tr.learner.update_minibatch(*batch(k))
-    for k in range(5):
-        step(k)
+    t1 = time.perf_counter()
+    tr.compute_gae()
+    tr.update()
     fence()
-    t0 = time.perf_counter()
-    for k in range(5, 5 + steps):
-        step(k)
-    fence()
-    t_upd = tmax(time.perf_counter() - t0)
+    t2 = time.perf_counter()
+    t_roll, t_upd = tmax(t1 - t0), tmax(t2 - t1)
+    steps = int(tr.stats["optimizer_steps"])
+    finite = bool(torch.isfinite(tr.stats["grad_norm"]).item())
     grad_bytes = tr.learner.bucket.grad.numel() * 4
-    graph_rate = None
-    if world == 1 and not force_pg:
-        # the same 512-sample step replayed from a hipGraph (one GPU only: the captured RCCL all-reduce is not validated)
-        try:
-            tr.learner.capture(mb, tr.obs_shape, torch.bfloat16, merged_batch=mb // 2)
-            for k in range(5):
-                tr.learner.update_minibatch_graph(*batch(k))
-            fence()
-            t0 = time.perf_counter()
-            for k in range(5, 5 + steps):
-                st = tr.learner.update_minibatch_graph(*batch(k))
-            fence()
-            graph_rate = steps / (time.perf_counter() - t0)
-            if not bool(torch.isfinite(st["grad_norm"]).item()):
-                graph_rate = "non-finite gradient norm"
-        except Exception as e:                      # the probe is optional: report, do not lose the bench line
-            graph_rate = f"failed: {type(e).__name__}: {e}"
+    fused = bool(tr.model._use_fused_tower(tr.obs_buf[0, :1, 0]))
     tr.env.close()
-    return {"optimizer_steps_per_s": steps / t_upd, "optimizer_steps_per_s_hipgraph": graph_rate,
-            "samples_per_optimizer_step": mb * world, "samples_per_gpu_per_step": mb,
-            "minibatch": "256 env-tick pairs = 512 agent samples per GPU; the centralised critic runs once per pair",
-            "train_samples_per_s": steps * mb * world / t_upd,
-            "rollout_env_steps_per_s": n_envs * horizon * world / t_roll, "rollout_envs": n_envs * world, "horizon": horizon,
+    del tr
+    torch.cuda.empty_cache()
+    env_steps = n_envs * horizon * world
+    return {"end_to_end_env_steps_per_s": env_steps / (t_roll + t_upd), "minibatch_per_gpu": minibatch,
+            "envs_per_gpu": n_envs, "horizon": horizon, "epochs": 3, "optimizer_steps": steps, "rollout_s": t_roll,
+            "gae_plus_update_s": t_upd, "rollout_env_steps_per_s": env_steps / t_roll, "optimizer_steps_per_s": steps / t_upd,
+            "train_samples_per_s": steps * minibatch * world / t_upd, "hipgraph_replay": bool(use_graph and not force_pg),
+            "finite": finite, "fused_actor_tower": fused,
             "grad_allreduce": (f"one RCCL all-reduce of the flat fp32 gradient bucket ({grad_bytes / 1e6:.1f} MB) per optimizer step"
-                               if (world > 1 or force_pg) else "none (1 GPU)"),
-            "network": "MAPPOAgent (ResNet actor + transformer critic), bf16 autocast; MIOpen NHWC convolutions + hipBLASLt + hand-written "
-                       "HIP attention (MFMA), add+LayerNorm and GroupNorm+GELU kernels",
+                               if (world > 1 or force_pg) else "none (1 GPU)")}
+
+
+def ppo_probe(layname, dev, rank=0, world=1, dist=None, n_envs=16384, horizon=32, large_minibatch=16384):
+    """The second half of BASELINE.json's metric: end-to-end MAPPO on BASELINE config 3 (smallCapture, 16 384 envs per GPU,
+    T = 32, 3 epochs), once at the reference's minibatch of 512 samples per GPU (pacman_mappo_resnet.py:18; replayed from a
+    hipGraph on one GPU, where the step is launch-bound) and once at a large minibatch (fewer, larger optimizer steps -- a
+    different optimisation schedule than the reference's, stated as such)."""
+    runs = []
+    for mb, graph in ((512, world == 1), (large_minibatch, False)):
+        try:
+            runs.append(e2e_probe(layname, dev, rank, world, dist, n_envs, horizon, mb, graph))
+        except Exception as e:                      # the probe must not lose the bench line
+            runs.append({"minibatch_per_gpu": mb, "error": f"{type(e).__name__}: {e}"})
+    ref, big = runs
+    return {"config": f"{layname}, {n_envs} envs/GPU, horizon {horizon}, 3 epochs, paired minibatches (the centralised critic runs once "
+                      "per env-tick pair), bf16 autocast, byte observation planes, in-kernel randomTeam opponent",
+            "end_to_end": runs,
+            "end_to_end_env_steps_per_s": big.get("end_to_end_env_steps_per_s"), "end_to_end_minibatch": large_minibatch,
+            "end_to_end_env_steps_per_s_mb512": ref.get("end_to_end_env_steps_per_s"),
+            "optimizer_steps_per_s": ref.get("optimizer_steps_per_s"), "samples_per_gpu_per_step": 512,
+            "rollout_env_steps_per_s": big.get("rollout_env_steps_per_s"),
+            "network": "MAPPOAgent: actor tower = one fused HIP forward kernel + two backward kernels on bf16 MFMA "
+                       "(csrc/pmx_actor.hip); critic = hand-written MFMA attention, add+LayerNorm kernels, hipBLASLt token GEMMs",
             "reference_cpu": "0.49 s per optimizer step (2 steps/s) and about 80 env-steps/s end to end on 8 host cores, smallCapture "
                              "(tools/time_reference.py, profiles/r01_cpu_reference_ratio.json)"}
 
@@ -264,27 +259,44 @@ def main():
     for k in range(args.steps):
         env.step(actions[k % n_act])
     prof = env.profile_end()
-    # third, short pass with the alternating sweep switched off (PMX_EXPAND_ALT is read at every launch): what the expansion
-    # kernel does when every byte has to go to HBM, i.e. without tick t+1 overwriting the tail of tick t in the Infinity Cache
-    prof_uni = None
+    # third pass, the one the roofline is quoted on: the alternating sweep switched off (pmx_set_tuning "expand_alt" 0), so that
+    # every byte of the planes has to reach HBM.  The default alternates the sweep direction, and a loop like this one -- the
+    # same buffer re-stepped with nothing in between -- then overwrites the tail of tick t while it is still in the 256 MiB
+    # Infinity Cache; that figure is reported separately as `cache_assisted`, it is not an HBM rate.
+    # fourth pass: the default sweep again, but with a CONSUMER between ticks that reads the planes and writes a rollout slot
+    # (what VecMAPPOTrainer.rollout does first with every tick's observations): the cache holds the consumer's traffic then.
+    k_uni = min(args.steps, 500)
+    env.set_tuning("expand_alt", 0)
+    t_uni0 = None
+    for k in range(20):
+        env.step(actions[k % n_act])
+    torch.cuda.synchronize(dev)
+    t_uni0 = time.perf_counter()
+    for k in range(k_uni):
+        env.step(actions[k % n_act])
+    torch.cuda.synchronize(dev)
+    tick_uni_s = (time.perf_counter() - t_uni0) / k_uni
+    env.profile_begin(k_uni + 8)
+    for k in range(k_uni):
+        env.step(actions[k % n_act])
+    prof_uni = env.profile_end()
+    env.set_tuning("expand_alt", -1)
+    prof_cons = None
     if not args.no_unidirectional:
-        k_uni = min(args.steps, 300)
-        prev_alt = os.environ.get("PMX_EXPAND_ALT")
-        os.environ["PMX_EXPAND_ALT"] = "0"
-        for k in range(20):
-            env.step(actions[k % n_act])
-        env.profile_begin(k_uni + 8)
-        for k in range(k_uni):
-            env.step(actions[k % n_act])
-        prof_uni = env.profile_end()
-        if prev_alt is None:
-            del os.environ["PMX_EXPAND_ALT"]
-        else:
-            os.environ["PMX_EXPAND_ALT"] = prev_alt
+        slots = torch.empty((4,) + tuple(env.obs.shape), dtype=env.obs.dtype, device=dev)
+        k_c = min(args.steps, 200)
+        for k in range(10):
+            env.step(actions[k % n_act]); slots[k % 4].copy_(env.obs)
+        env.profile_begin(k_c + 8)
+        for k in range(k_c):
+            env.step(actions[k % n_act]); slots[k % 4].copy_(env.obs)
+        prof_cons = env.profile_end()
+        del slots
     e = ELEM[args.obs]
     expand_bytes = n_envs * 4 * 8 * H * W * e                      # algorithmic bytes of one expansion launch
-    expand_s = prof["expand_ms"] / 1e3 / max(prof["expand_launches"], 1)
-    rule_s = prof["rule_ms"] / 1e3 / max(prof["rule_launches"], 1)
+    expand_alt_s = prof["expand_ms"] / 1e3 / max(prof["expand_launches"], 1)
+    expand_s = prof_uni["expand_ms"] / 1e3 / max(prof_uni["expand_launches"], 1)
+    rule_s = prof_uni["rule_ms"] / 1e3 / max(prof_uni["rule_launches"], 1)
     achieved = expand_bytes / expand_s / 1e9
     # same-process, same-device calibration: a pure streaming write of the same number of bytes (torch fill_)
     cal = torch.empty(expand_bytes // 4, dtype=torch.float32, device=dev)
@@ -324,18 +336,26 @@ def main():
             "agent_steps_per_s": 4 * value,
             "algorithmic_bytes_per_env_step": B,
             "tick_GBps": value / world * B / 1e9,
+            "tick_all_bytes_to_hbm": {"us_per_tick": tick_uni_s * 1e6, "GBps": n_envs * B / tick_uni_s / 1e9,
+                                      "frac_of_peak": n_envs * B / tick_uni_s / 1e9 / HBM_PEAK_GBS,
+                                      "note": "whole tick (rule + expansion kernels, host launch path) with the sweep direction fixed"},
             "roofline": {"bound": "hbm", "kernel": "pmx_expand_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "measured_with": "sweep direction fixed (pmx_set_tuning expand_alt 0): every byte of the planes reaches HBM",
                          "traffic_scope": "PMC TCC FETCH_SIZE/WRITE_SIZE = L2 <-> fabric requests; the Infinity Cache sits behind them",
                          "algorithmic_bytes_per_launch": expand_bytes, "avg_launch_us": expand_s * 1e6,
-                         "launches": prof["expand_launches"], "rule_kernel_avg_us": rule_s * 1e6,
+                         "launches": prof_uni["expand_launches"], "rule_kernel_avg_us": rule_s * 1e6,
                          "same_device_fill_GBps": write_ceiling,
-                         "unidirectional_sweep": None if prof_uni is None else {
-                             "avg_launch_us": prof_uni["expand_ms"] * 1e3 / max(prof_uni["expand_launches"], 1),
-                             "achieved": expand_bytes / (prof_uni["expand_ms"] / 1e3 / max(prof_uni["expand_launches"], 1)) / 1e9,
-                             "note": "same kernel with PMX_EXPAND_ALT=0: every tick walks the planes in the same direction, so all "
-                                     "bytes reach HBM; the default alternates the direction and tick t+1 overwrites the tail of tick t "
-                                     "while it is still in the 256 MiB Infinity Cache (those lines never cost an HBM write)"}},
+                         "cache_assisted": {
+                             "avg_launch_us": expand_alt_s * 1e6, "GBps": expand_bytes / expand_alt_s / 1e9,
+                             "note": "the default path in THIS loop (same buffer re-stepped, nothing in between): the sweep direction "
+                                     "alternates and tick t+1 overwrites the tail of tick t while it is still in the 256 MiB Infinity "
+                                     "Cache; algorithmic bytes / time, NOT an HBM rate (`value` and `ms_per_step` are from this path)"},
+                         "with_consumer": None if prof_cons is None else {
+                             "avg_launch_us": prof_cons["expand_ms"] * 1e3 / max(prof_cons["expand_launches"], 1),
+                             "GBps": expand_bytes / (prof_cons["expand_ms"] / 1e3 / max(prof_cons["expand_launches"], 1)) / 1e9,
+                             "note": "default path with a copy of the planes into a rollout slot between ticks (reads them, writes as "
+                                     "many bytes elsewhere)"}},
             "obs_checksum": checksum,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -9,7 +9,13 @@ import os as _os
 # graph returns a non-finite bias gradient; eager and DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 runs are clean, DESIGN.md
 # section 5).  The runtime reads the switch when HIP initialises, so it is set here, before this package touches the
 # GPU; a process that initialised HIP earlier must export it itself (mappo.graph_replay_safe() checks the variable).
+_preset = _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE")
 _os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+import torch as _torch
+
+# True only if the runtime can have seen the switch: it was exported by the user (who then owns the "before HIP initialises"
+# part), or HIP had not been initialised in this process when the line above set it.  mappo.PPOLearner.graph_replay_safe().
+GRAPH_REPLAY_OK = _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0" and (_preset == "0" or not _torch.cuda.is_initialized())
 
 from . import _lib
 from ._lib import PmxError

@@ -64,6 +64,7 @@ PROTOTYPES = [
     ("pmx_maze_distances", C.c_int, [_VP, _VP, _VP, C.POINTER(_I32), _VP]),
     ("pmx_maze_distances_layout", C.c_int, [_VP, _I32, _VP, _VP, C.POINTER(_I32), _VP]),
     ("pmx_profile_begin", C.c_int, [_VP, _I32]),
+    ("pmx_set_tuning", C.c_int, [_VP, C.c_char_p, _I32]),
     ("pmx_profile_end", C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(_I32), C.POINTER(C.c_double), C.POINTER(_I32)]),
     ("pmx_gae", C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, C.c_double, C.c_double, _VP, _VP, _VP]),
     ("pmx_ln32_forward", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_float, _I32, _VP]),

@@ -13,7 +13,8 @@ extern "C" hipError_t pmx_launch_rule(const PmxTickParams *p, int H, hipStream_t
 extern "C" hipError_t pmx_launch_rule_agent(const PmxTickParams *p, int H, int agent, hipStream_t st);
 extern "C" hipError_t pmx_launch_reset(const PmxTickParams *p, int H, hipStream_t st);
 extern "C" hipError_t pmx_launch_successor(const PmxTickParams *p, int H, int agent, hipStream_t st);
-extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, int dtype, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, const PmxExpandTuning *tune, int dtype, hipStream_t st, hipEvent_t ev0,
+                                         hipEvent_t ev1);
 extern "C" hipError_t pmx_launch_maze(const PmxLayoutDev *lay_dev, const int16_t *cell_index_dev, int n_cells,
                                       const int8_t *cells_dev, uint8_t *dist_dev, hipStream_t st);
 
@@ -42,6 +43,7 @@ struct pmx_env {
     // optional per-kernel timing (pmx_profile_begin/end): pairs of events around each launch
     bool profiling;
     uint64_t expand_launches = 0;   // parity selects the direction of the expansion sweep
+    PmxExpandTuning tune;           // launch tuning, read from the environment once at pmx_create
     std::vector<hipEvent_t> ev_rule, ev_expand;
     size_t ev_rule_used, ev_expand_used;
 };
@@ -156,13 +158,12 @@ int launch_expand(pmx_env *env, void *obs, bool from_snapshots, int single_agent
         for (int i = 0; i < 4; ++i) x.emit[i] = env->emit[i];
     }
     if (single_agent < 0) {
-        // alternate the direction of the sweep over the planes from tick to tick (see pmx_launch_expand); PMX_EXPAND_ALT=0
-        // switches it off for A/B measurements
-        const char *o = getenv("PMX_EXPAND_ALT");
-        if (!o || atoi(o) != 0) x.reverse = (int32_t)(env->expand_launches++ & 1);
+        // alternate the direction of the sweep over the planes from tick to tick (see pmx_launch_expand);
+        // pmx_set_tuning(env, "expand_alt", 0) switches it off (the all-bytes-to-HBM measurement of bench.py)
+        if (env->tune.alt != 0) x.reverse = (int32_t)(env->expand_launches++ & 1);
     }
     hipEvent_t *ev = prof_pair(env, true);       // profiling: the dispatch's own start / stop timestamps
-    HIP_TRY(pmx_launch_expand(&x, env->cfg.obs_dtype, st, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr));
+    HIP_TRY(pmx_launch_expand(&x, &env->tune, env->cfg.obs_dtype, st, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr));
     return PMX_OK;
 }
 
@@ -268,6 +269,13 @@ int pmx_create(const pmx_config *cfg, pmx_env **out)
     if (cfg->enable_bots && dist_bytes > ((size_t)1 << 31)) { delete env; return fail(PMX_ERR_UNSUPPORTED, "enable_bots: the layouts' distance matrices exceed 2 GiB"); }
     const bool with_bots = cfg->enable_bots != 0;
     env->cfg = *cfg;
+    {   // experiment overrides of the expansion launch, read HERE once, not on the tick path
+        auto env_int = [](const char *name) { const char *o = getenv(name); return o ? atoi(o) : -1; };
+        env->tune.alt = env_int("PMX_EXPAND_ALT");
+        env->tune.nt = env_int("PMX_EXPAND_NT");
+        env->tune.lds_pad = env_int("PMX_EXPAND_LDS_PAD");
+        env->tune.lut = env_int("PMX_EXPAND_LUT");
+    }
     env->cfg.wall_rows = env->cfg.food_rows = env->cfg.cap_rows = nullptr;
     env->cfg.starts = nullptr;
     env->cfg.layout_index = nullptr;
@@ -424,6 +432,19 @@ int pmx_observe(pmx_env *env, void *obs_dev, uint8_t *legal_dev, void *stream)
 }
 
 // ---- per-kernel timing for bench.py (not part of the reference surface) -----------------------------------------
+// Launch tuning of the expansion kernel for A/B measurements: key "expand_alt" | "expand_nt" | "expand_lds_pad" | "expand_lut",
+// value -1 = built-in choice.
+int pmx_set_tuning(pmx_env *env, const char *key, int32_t value)
+{
+    if (!env || !key) return fail(PMX_ERR_INVALID, "pmx_set_tuning: null argument");
+    if (!strcmp(key, "expand_alt")) env->tune.alt = value;
+    else if (!strcmp(key, "expand_nt")) env->tune.nt = value;
+    else if (!strcmp(key, "expand_lds_pad")) env->tune.lds_pad = value;
+    else if (!strcmp(key, "expand_lut")) env->tune.lut = value;
+    else return fail(PMX_ERR_INVALID, "pmx_set_tuning: unknown key %s", key);
+    return PMX_OK;
+}
+
 // Between begin and end every pmx_step / pmx_observe / pmx_reset records a HIP event pair around its rule-kernel and
 // expansion-kernel launches, on the stream the kernels run on.  pmx_profile_end synchronises those events and returns
 // the summed kernel durations in milliseconds and the launch counts.

@@ -84,3 +84,12 @@ struct PmxExpandParams {
     int32_t lay_H, lay_W;        // host-side copies of the common layout dimensions (launch sizing)
     int32_t reverse;             // 1: walk the blocks from the highest address down (alternate ticks, see pmx_launch_expand)
 };
+
+// Host-side launch tuning of the expansion kernel: -1 = the built-in choice.  Filled once per handle at pmx_create (from the
+// PMX_EXPAND_* environment variables, for experiments) and changed through pmx_set_tuning; never read at launch time.
+struct PmxExpandTuning {
+    int32_t alt = -1;            // alternate the sweep direction from tick to tick
+    int32_t nt = -1;             // non-temporal stores
+    int32_t lds_pad = -1;        // dynamic-LDS reservation per block (occupancy cap), bytes
+    int32_t lut = -1;            // LDS look-up-table expansion
+};

@@ -895,7 +895,8 @@ extern "C" hipError_t pmx_launch_reset(const PmxTickParams *p, int H, hipStream_
     return hipGetLastError();
 }
 
-extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, int dtype, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1)
+extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, const PmxExpandTuning *tune, int dtype, hipStream_t st, hipEvent_t ev0,
+                                         hipEvent_t ev1)
 {
     const long waves = (long)p->N * p->n_emit;
     const unsigned blocks = (unsigned)((waves + 3) / 4);
@@ -921,14 +922,14 @@ extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, int dtype, hip
     const size_t elem = dtype == 0 ? 4 : (dtype == 1 ? 2 : 1);
     const size_t bytes = (size_t)waves * 8 * p->lay_H * p->lay_W * elem;
     bool nt = elem == 1 || (elem == 2 && bytes > ((size_t)512 << 20)) || (elem == 4 && bytes > ((size_t)900 << 20));
-    if (const char *o = getenv("PMX_EXPAND_NT")) nt = atoi(o) != 0;      // experiment override
+    if (tune && tune->nt >= 0) nt = tune->nt != 0;                        // experiment override (pmx_set_tuning)
     size_t lds_pad = (nt && elem == 4) ? 40000 : 0;
-    if (const char *o = getenv("PMX_EXPAND_LDS_PAD")) lds_pad = (size_t)atoi(o);   // experiment override
+    if (tune && tune->lds_pad >= 0) lds_pad = (size_t)tune->lds_pad;      // experiment override
     PmxExpandParams q = *p;
     if (nt) q.reverse = 0;
     p = &q;
     bool use_lut = true;
-    if (const char *o = getenv("PMX_EXPAND_LUT")) use_lut = atoi(o) != 0;    // experiment override
+    if (tune && tune->lut >= 0) use_lut = tune->lut != 0;                 // experiment override
 #define PMX_EXPAND_LAUNCH2(DT, NTV, LUTV)                                                                               \
     do {                                                                                                                \
         if (ev0) hipExtLaunchKernelGGL((pmx_expand_kernel<DT, NTV, LUTV>), dim3(blocks), dim3(PMX_BLOCK), (uint32_t)lds_pad, st, ev0, ev1, 0, *p); \

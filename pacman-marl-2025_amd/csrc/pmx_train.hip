@@ -723,7 +723,10 @@ extern "C" int pmx_attn8_forward(const void *qkv_dev, void *out_dev, float *lse_
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int S_pad = (S + 31) & ~31;
     const size_t lds = (size_t)4 * 2 * S_pad * 8 * sizeof(short);
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {};          // the attribute belongs to the function ON THE CURRENT DEVICE
+    int cur_dev = 0;
+    if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev < 0 || cur_dev >= 64) return PMX_ERR_HIP;
+    bool &attr_set = attr_set_dev[cur_dev];
     if (lds > 65536 && !attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(pmx_attn8_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return PMX_ERR_HIP;
@@ -909,7 +912,10 @@ extern "C" int pmx_attn8_backward(const void *qkv_dev, const void *out_dev, cons
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int S_pad = (S + 31) & ~31;
     const size_t lds = (size_t)4 * ((size_t)3 * 8 * S_pad * sizeof(short) + (size_t)2 * S_pad * sizeof(float));
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {};          // the attribute belongs to the function ON THE CURRENT DEVICE
+    int cur_dev = 0;
+    if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev < 0 || cur_dev >= 64) return PMX_ERR_HIP;
+    bool &attr_set = attr_set_dev[cur_dev];
     if (lds > 65536 && !attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(pmx_attn8_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return PMX_ERR_HIP;

@@ -339,6 +339,8 @@ class MAPPOAgent(nn.Module):
                 m.bias.data.fill_(0.0)
 
     fused_tower = True      # use the fused actor-tower kernels where they apply (bf16 on the GPU, supported board size)
+    tower_pack = None       # packed tower parameters for inference, set by a caller that knows the weights are frozen
+                            # (VecMAPPOTrainer.rollout); None = pack on every call
 
     def _use_fused_tower(self, obs):
         if not (self.fused_tower and obs.is_cuda and obs.dim() == 4 and obs.dtype in (torch.bfloat16, torch.uint8)):
@@ -353,8 +355,13 @@ class MAPPOAgent(nn.Module):
             # one kernel for the whole convolutional tower (csrc/pmx_actor.hip); its output is channels-last, nn.Flatten's
             # order is channel-major
             from . import actor_tower
-            feat = actor_tower.actor_tower(self.actor_backbone, obs)             # [B, H*W, 32] bf16
+            if self.tower_pack is not None and not torch.is_grad_enabled():
+                feat = actor_tower.tower_forward(obs, self.tower_pack)
+            else:
+                feat = actor_tower.actor_tower(self.actor_backbone, obs)         # [B, H*W, 32] bf16
             return self.actor_head(feat.permute(0, 2, 1).reshape(feat.shape[0], -1))
+        if obs.dtype == torch.uint8:            # byte planes are an input format of the fused tower only
+            obs = obs.to(torch.bfloat16 if (obs.is_cuda and torch.is_autocast_enabled()) else torch.float32)
         if obs.is_cuda and obs.dtype == torch.bfloat16 and obs.dim() == 4:
             # channels-last end to end: MIOpen's NHWC bf16 implicit-GEMM convolutions and the NHWC GroupNorm kernels then
             # need no layout transposes; nn.Flatten still flattens in logical (C, H, W) order, one copy at the end
@@ -363,6 +370,8 @@ class MAPPOAgent(nn.Module):
 
     def value(self, merged_obs):
         """merged_obs [B,8,H,W] -> [B] (pacman_mappo_resnet.py:160-170)"""
+        if merged_obs.dtype == torch.uint8:
+            merged_obs = merged_obs.to(torch.bfloat16 if (merged_obs.is_cuda and torch.is_autocast_enabled()) else torch.float32)
         x = self.pos_encoder(self.critic_projector(merged_obs))
         x = x.flatten(2).permute(2, 0, 1)                                # [H*W, B, d]
         x = self.critic_transformer(x).mean(dim=0)
@@ -545,9 +554,12 @@ class PPOLearner:
     # ---- hipGraph capture of the whole optimizer step (launch-bound at the reference's minibatch of 512) ----------
     @staticmethod
     def graph_replay_safe():
-        """hipGraph replay is only trusted with ROCclr's AQL packet capture switched off (see the package __init__)."""
+        """hipGraph replay is only trusted with ROCclr's AQL packet capture switched off, and only if the runtime can have
+        read the switch: set before HIP initialised (see the package __init__, which records that at import)."""
         import os
-        return os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
+        import sys
+        pkg = sys.modules.get(__name__.rsplit(".", 1)[0])
+        return os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0" and bool(getattr(pkg, "GRAPH_REPLAY_OK", False))
 
     def capture(self, batch, obs_shape, in_dtype, clip_eps=CLIP_EPS, ent_coef=ENT_COEF_START, merged_batch=None):
         """Record zero_grad -> forward -> backward -> (all-reduce) -> clip -> Adam -> EMA for a fixed minibatch shape into

@@ -53,14 +53,22 @@ def canonicalize_obs(o):
 
 
 class VecMAPPOTrainer:
-    def __init__(self, layout, n_envs, horizon=32, minibatch=512, epochs=UPDATE_EPOCHS, obs_dtype="bfloat16",
+    def __init__(self, layout, n_envs, horizon=32, minibatch=512, epochs=UPDATE_EPOCHS, obs_dtype=None,
                  device="cuda:0", seed=0, rank=0, world_size=1, process_group=None, total_updates=2000, length=300,
-                 use_autocast=True, opponent="random", use_graph=False, algorithm="mappo", paired_minibatches=True, flat_bf16=False, curriculum_scale=1.0):
+                 use_autocast=True, opponent="random", use_graph=False, algorithm="mappo", paired_minibatches=True, flat_bf16=False, curriculum_scale=1.0,
+                 env=None):
         self.device = torch.device(device)
         self.rank, self.world_size = rank, world_size
-        self.env = PmxVecEnv(layout, n_envs, length=length, reward_forLegalAction=True, defenceReward=True,
-                             auto_reset=True, obs_dtype=obs_dtype, device=self.device, seed=seed * 1000003 + rank,
-                             bots=opponent in ("baseline", "curriculum"))
+        if obs_dtype is None:
+            # byte planes on the bf16 path: the values are small integers, the fused actor tower reads bytes directly and
+            # the rollout buffers are half the size; float32 planes (the reference's dtype) on the float32 path
+            obs_dtype = "uint8" if use_autocast else "float32"
+        # `env`: an already built vectorised env (anything with PmxVecEnv's surface).  The host-side tests pass a stand-in to
+        # drive update() / the opponent schedule without a GPU; the product always builds the HIP env here, which raises
+        # without a GPU
+        self.env = env if env is not None else PmxVecEnv(
+            layout, n_envs, length=length, reward_forLegalAction=True, defenceReward=True, auto_reset=True, obs_dtype=obs_dtype,
+            device=self.device, seed=seed * 1000003 + rank, bots=opponent in ("baseline", "curriculum"))
         self.N, self.T = n_envs, horizon
         self.minibatch, self.epochs = minibatch, epochs
         # "mappo": centralised critic on merge_obs_for_critic of the two learners (the reference).  "ippo": the same network
@@ -99,8 +107,10 @@ class VecMAPPOTrainer:
         self.opponent_pool = deque(maxlen=OPPONENT_POOL_SIZE)
         self.opponent_pool.append(self.learner.ema_state_dict())
         self.opponent_mode = opponent                              # "random" | "baseline" | "self" | "pool" | "curriculum"
-        self.gen = torch.Generator(device=self.device).manual_seed(seed * 7919 + rank)
-        self.np_rng = np.random.RandomState(seed * 31 + rank)
+        self.gen = torch.Generator(device=self.device).manual_seed(seed * 7919 + rank)   # action sampling, minibatch order: per rank
+        # opponent mode / side / pool draws: the SAME stream on every rank, so that all ranks run the same kind of rollout
+        # (an extra opponent forward per tick on some ranks only would make the others wait at every gradient all-reduce)
+        self.np_rng = np.random.RandomState(seed * 31)
         dt, dev, N, T = self.env.obs_torch_dtype, self.device, n_envs, horizon
         self.obs_buf = torch.zeros((T, N, 2) + self.obs_shape, dtype=dt, device=dev)
         self.merged_buf = torch.zeros((T, N) + self.obs_shape, dtype=dt, device=dev)
@@ -131,8 +141,20 @@ class VecMAPPOTrainer:
 
     # ---------------------------------------------------------------------------------------------------------
     def _net_in(self, x):
-        """Observation tensors are small integers: hand the network bf16 under autocast, fp32 otherwise."""
-        return x.to(torch.bfloat16) if self.autocast_dtype is not None else x.float()
+        """Observation tensors are small integers: under autocast the network takes bytes or bf16 as they are (the fused
+        actor tower reads either, the critic converts on entry), fp32 otherwise."""
+        if self.autocast_dtype is not None:
+            return x if x.dtype in (torch.uint8, torch.bfloat16) else x.to(torch.bfloat16)
+        return x.float()
+
+    def _freeze_tower_packs(self, on):
+        """The rollout runs thousands of inference calls on frozen weights: pack the actor towers' parameters once."""
+        from . import actor_tower
+        H, W = self.obs_shape[1], self.obs_shape[2]
+        for m in (self.model, self.opponent_model):
+            m.tower_pack = None
+            if on and self.autocast_dtype is not None and m.fused_tower and actor_tower.tower_supported(H, W):
+                m.tower_pack = actor_tower.pack_params(actor_tower._tower_params(m.actor_backbone))
 
     def _forward_policy(self, model, obs2, merged, want_value):
         ctx = torch.autocast(device_type=self.device.type, dtype=self.autocast_dtype) if self.autocast_dtype else _NullCtx()
@@ -166,6 +188,7 @@ class VecMAPPOTrainer:
     def rollout(self):
         env, N, T = self.env, self.N, self.T
         mode, red = self._pick_opponent()
+        self._freeze_tower_packs(True)
         learner_ids = [0, 2] if red else [1, 3]
         opp_ids = [1, 3] if red else [0, 2]
         team = 0 if red else 1
@@ -223,6 +246,7 @@ class VecMAPPOTrainer:
                 self.last_value = self.model.value(self._net_in(last_merged)).float()[:, None].expand(N, 2).contiguous()
             else:
                 self.last_value = self.model.value(self._net_in(lo.reshape((-1,) + self.obs_shape))).float().view(N, 2)
+        self._freeze_tower_packs(False)
         self.stats.update(opponent=mode, play_as_red=red, rollout_reward=ep_ret, episodes=n_done, wins=n_win)
 
     def compute_gae(self):
@@ -233,7 +257,8 @@ class VecMAPPOTrainer:
                                         last.data_ptr(), T, n, mappo.GAMMA, mappo.GAE_LAMBDA, self.adv_buf.data_ptr(),
                                         self.ret_buf.data_ptr(), st), "pmx_gae")
 
-    def update(self):
+    def update(self, max_steps=None):
+        """The PPO epochs over the rollout buffers.  max_steps stops after that many optimizer steps (warm-up runs only)."""
         lr, ent_coef, clip_eps = mappo.schedule(self.update_idx, self.total_updates)
         self.learner.set_lr(lr)
         S = self.T * self.N * 2
@@ -243,6 +268,10 @@ class VecMAPPOTrainer:
         adv, ret = self.adv_buf.view(S), self.ret_buf.view(S)
         agg = None
         steps = 0
+        snap = None
+        if self.use_graph:      # a bad replay must not leave NaNs in the weights, the Adam moments and the EMA: keep a copy to go back to
+            L = self.learner
+            snap = [t.clone() for t in (L.bucket.data, L.exp_avg, L.exp_avg_sq, L.ema)] + [L.step_count]
         for _ in range(self.epochs):
             if self.paired:
                 pperm = torch.randperm(S // 2, device=self.device, generator=self.gen)
@@ -255,7 +284,7 @@ class VecMAPPOTrainer:
                 else:
                     mb = perm[s0:s0 + self.minibatch]
                 if self.use_graph and not self._graph_ready:
-                    self.learner.capture(self.minibatch, self.obs_shape, torch.bfloat16 if self.autocast_dtype is not None else torch.float32,
+                    self.learner.capture(self.minibatch, self.obs_shape, self._net_in(obs[:1]).dtype,
                                          clip_eps, ent_coef, merged_batch=self.minibatch // 2 if self.paired else None)
                     self._graph_ready = True
                 step = self.learner.update_minibatch_graph if self.use_graph else self.learner.update_minibatch
@@ -263,9 +292,19 @@ class VecMAPPOTrainer:
                 st = step(self._net_in(obs[mb]), self._net_in(critic_in), act[mb], logp[mb], adv[mb], ret[mb], clip_eps, ent_coef)
                 steps += 1
                 agg = {k: v.clone() for k, v in st.items()} if agg is None else {k: agg[k] + st[k] for k in agg}
+                if max_steps is not None and steps >= max_steps:
+                    break
+            if max_steps is not None and steps >= max_steps:
+                break
         self.stats.update({k: v / steps for k, v in agg.items()})
         if self.use_graph and not bool(torch.isfinite(self.stats["grad_norm"]).item()):
-            raise RuntimeError("non-finite gradient norm from the graph-replayed optimizer step")
+            L = self.learner
+            for t, v in zip((L.bucket.data, L.exp_avg, L.exp_avg_sq, L.ema), snap[:4]):
+                t.copy_(v)
+            L.step_count = snap[4]
+            L._refresh_bf16()
+            raise RuntimeError("non-finite gradient norm from the graph-replayed optimizer step; the learner was restored to "
+                               "its state before this update")
         self.stats.update(lr=lr, ent_coef=ent_coef, clip_eps=clip_eps, optimizer_steps=steps)
         if self.update_idx % OPPONENT_UPDATE_FREQ == 0:
             self.opponent_pool.append(self.learner.ema_state_dict())
@@ -282,18 +321,28 @@ class VecMAPPOTrainer:
         torch.save(self.learner.ema_state_dict(), path)
 
     def save_full(self, path):
-        """Full resume state, which the reference lacks: weights, EMA, Adam moments, pool, counters."""
+        """Full resume state, which the reference lacks: weights, EMA, Adam moments, opponent pool,
+        counters and both random streams -- tensors, numbers and strings only, so that it loads with weights_only=True.
+        The games themselves are not saved: a resumed run starts its envs from fresh episodes."""
+        kind, keys, pos, has_gauss, cached = self.np_rng.get_state()
         torch.save({"data": self.learner.bucket.data, "ema": self.learner.ema, "exp_avg": self.learner.exp_avg,
-                    "exp_avg_sq": self.learner.exp_avg_sq, "step": self.learner.step_count, "update": self.update_idx,
-                    "pool": list(self.opponent_pool), "gen": self.gen.get_state(), "np_rng": self.np_rng.get_state()}, path)
+                    "exp_avg_sq": self.learner.exp_avg_sq, "step": int(self.learner.step_count), "update": int(self.update_idx),
+                    "total_updates": int(self.total_updates), "pool": list(self.opponent_pool), "gen": self.gen.get_state(),
+                    "np_rng": {"kind": str(kind), "keys": torch.from_numpy(np.asarray(keys, dtype=np.int64)), "pos": int(pos),
+                               "has_gauss": int(has_gauss), "cached_gaussian": float(cached)}}, path)
 
     def load_full(self, path):
-        ck = torch.load(path, map_location=self.device, weights_only=False)
+        ck = torch.load(path, map_location=self.device, weights_only=True)
+        if int(ck["total_updates"]) != int(self.total_updates):
+            raise ValueError(f"checkpoint was written for a schedule of {ck['total_updates']} updates, this trainer has {self.total_updates}")
         self.learner.bucket.data.copy_(ck["data"]); self.learner.ema.copy_(ck["ema"])
         self.learner.exp_avg.copy_(ck["exp_avg"]); self.learner.exp_avg_sq.copy_(ck["exp_avg_sq"])
-        self.learner.step_count, self.update_idx = ck["step"], ck["update"]
+        self.learner.step_count, self.update_idx = int(ck["step"]), int(ck["update"])
         self.opponent_pool = deque(ck["pool"], maxlen=OPPONENT_POOL_SIZE)
-        self.gen.set_state(ck["gen"].cpu()); self.np_rng.set_state(ck["np_rng"])
+        self.gen.set_state(ck["gen"].cpu())
+        r = ck["np_rng"]
+        self.np_rng.set_state((r["kind"], r["keys"].cpu().numpy().astype(np.uint32), int(r["pos"]), int(r["has_gauss"]),
+                               float(r["cached_gaussian"])))
         self.learner._refresh_bf16()
 
 

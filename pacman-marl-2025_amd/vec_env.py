@@ -178,6 +178,10 @@ class PmxVecEnv:
     def profile_begin(self, max_launches):
         _lib.check(self.lib.pmx_profile_begin(self.handle, int(max_launches)), "pmx_profile_begin")
 
+    def set_tuning(self, key, value):
+        """Launch tuning of the expansion kernel for A/B measurements (pmx_set_tuning): "expand_alt", "expand_nt", ..."""
+        _lib.check(self.lib.pmx_set_tuning(self.handle, key.encode(), int(value)), "pmx_set_tuning")
+
     def profile_end(self):
         """-> dict(rule_ms, rule_launches, expand_ms, expand_launches): summed kernel times from HIP events."""
         rm, em, rn, en = C.c_double(), C.c_double(), C.c_int32(), C.c_int32()

@@ -327,3 +327,87 @@ def test_evaluate_vectorized_runs_and_random_policy_loses_to_baseline():
     assert np.isfinite(mean) and np.isfinite(std) and wr < 0.2          # an untrained argmax policy does not beat the reflex bots
     mean_r, _, wr_r = trainer.evaluate_vectorized(model, layout="smallCapture", n_envs=256, opponent="random", length=60)
     assert np.isfinite(mean_r) and 0.0 <= wr_r <= 1.0
+
+
+def test_bf16_autocast_loss_tracks_the_reference_fixture():
+    """The production path (bf16 autocast, fused actor tower, hand-written attention / LayerNorm kernels) on the G7 batch:
+    BASELINE.json's 1e-4 is the float32 figure (tests above); what bf16 costs is stated here -- policy / value / total loss
+    and the mean entropy within 2e-2 relative of the reference's float32 numbers, per-sample log-probabilities within 3e-2
+    absolute."""
+    from pmx import mappo
+    from test_mappo_cpu import closed_form_weights, _golden_batch
+    d, meta, obs, merged, act, old_logp, adv, ret = _golden_batch()
+    model = mappo.MAPPOAgent(tuple(obs.shape[1:]), 5, 2)
+    closed_form_weights(model)
+    model = model.cuda()
+    c = lambda x: x.cuda()
+    for in_dtype in (torch.bfloat16, torch.uint8):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            assert model._use_fused_tower(c(obs).to(in_dtype))
+            loss, stats = mappo.ppo_loss(model, c(obs).to(in_dtype), c(merged).to(in_dtype), c(act), c(old_logp), c(adv), c(ret),
+                                         meta["clip_eps"], meta["ent_coef"])
+            vals, logp, ent = model.evaluate(c(obs).to(in_dtype), c(merged).to(in_dtype), c(act))
+        for k in ("pg", "vl"):
+            assert abs(float(stats[k]) - float(d[k])) <= 2e-2 * abs(float(d[k])) + 1e-4, (k, float(stats[k]), float(d[k]))
+        assert abs(float(loss) - float(d["loss"])) <= 2e-2 * abs(float(d["loss"])) + 1e-4
+        assert abs(float(ent.mean()) - float(np.mean(d["entropy"]))) <= 2e-2 * float(np.mean(d["entropy"]))
+        assert np.abs(logp.float().cpu().numpy() - d["logp"]).max() <= 3e-2
+
+
+def test_curriculum_and_pool_rollouts_on_the_gpu():
+    """opponent="curriculum" through its three phases and opponent="pool": every mode's rollout (in-kernel randomTeam and
+    baselineTeam, self-play, a pool snapshot; the learner on either colour) fills finite buffers, and a full update runs."""
+    from pmx import trainer
+    tr = trainer.VecMAPPOTrainer("smallCapture", n_envs=128, horizon=6, minibatch=256, epochs=1, seed=11, length=30,
+                                 opponent="curriculum", curriculum_scale=0.05, total_updates=100)
+    seen, sides = set(), set()
+    for idx in [0, 5] + [20] * 40 + [60] * 80:                     # phase thresholds at updates 10 and 40
+        if {"random", "baseline", "self", "pool"} <= seen and sides == {True, False}:
+            break
+        tr.update_idx = idx
+        tr.rollout()
+        mode, red = tr.stats["opponent"], tr.stats["play_as_red"]
+        assert (idx <= 10 and mode == "random") or (10 < idx <= 40 and mode in ("random", "baseline")) or idx > 40
+        seen.add(mode)
+        if mode in ("self", "pool"):
+            sides.add(red)
+        for buf in (tr.rew_buf, tr.val_buf, tr.logp_buf):
+            assert torch.isfinite(buf).all()
+        assert int(tr.act_buf.min()) >= 0 and int(tr.act_buf.max()) <= 4
+    assert seen == {"random", "baseline", "self", "pool"} and sides == {True, False}
+    tr.compute_gae()
+    tr.update()
+    assert torch.isfinite(tr.stats["loss"]) and torch.isfinite(tr.stats["grad_norm"])
+    tr.env.close()
+    tp = trainer.VecMAPPOTrainer("smallCapture", n_envs=64, horizon=4, minibatch=128, epochs=1, seed=12, length=30, opponent="pool")
+    for _ in range(3):
+        st = tp.train_update()
+        assert st["opponent"] == "pool" and torch.isfinite(st["loss"])
+    assert len(tp.opponent_pool) == 2                              # the initial snapshot + the one taken at update 0
+    tp.env.close()
+
+
+def test_full_checkpoint_resume_on_the_gpu(tmp_path):
+    """save_full / load_full with device tensors and the device generator: the restored state is exact and the generator
+    continues with the same draws; the update after a reload follows the original one to within what the float atomics of
+    the weight-gradient kernels allow (the bit-identical continuation is shown on the CPU, tests/test_mappo_cpu.py)."""
+    from pmx import trainer
+    mk = lambda: trainer.VecMAPPOTrainer("smallCapture", n_envs=64, horizon=4, minibatch=128, epochs=1, seed=21, length=30,
+                                         opponent="random", total_updates=30)
+    a = mk()
+    a.train_update()
+    a.rollout(); a.compute_gae()
+    path = str(tmp_path / "full.pt")
+    a.save_full(path)
+    b = mk()
+    b.load_full(path)
+    for k in ("obs_buf", "merged_buf", "act_buf", "logp_buf", "adv_buf", "ret_buf"):
+        getattr(b, k).copy_(getattr(a, k))
+    assert torch.equal(a.learner.bucket.data, b.learner.bucket.data) and torch.equal(a.learner.exp_avg, b.learner.exp_avg)
+    assert torch.equal(a.learner.exp_avg_sq, b.learner.exp_avg_sq) and torch.equal(a.learner.ema, b.learner.ema)
+    assert torch.equal(a.gen.get_state(), b.gen.get_state()) and a.learner.step_count == b.learner.step_count
+    a.update(); b.update()
+    diff = (a.learner.bucket.data - b.learner.bucket.data).abs()
+    assert float(diff.max()) <= 1e-3 and float(diff.mean()) <= 2e-5, (float(diff.max()), float(diff.mean()))
+    assert torch.equal(a.gen.get_state(), b.gen.get_state())
+    a.env.close(); b.env.close()

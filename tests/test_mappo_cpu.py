@@ -184,3 +184,156 @@ def test_paired_minibatch_loss_equals_expanded_loss():
     for x, y in zip(ga, gb):
         if x is not None:
             assert torch.allclose(x, y, rtol=1e-4, atol=1e-6)
+
+
+class _StubEnv:
+    """Stand-in for PmxVecEnv in host-side tests of VecMAPPOTrainer (update / opponent schedule): layout + zero observations."""
+
+    def __init__(self, layout, n_envs):
+        from pmx.layout import get_layout
+        self.layout = get_layout(layout)
+        self.obs_torch_dtype = torch.float32
+        self.n_envs = n_envs
+
+    def reset(self):
+        return torch.zeros((self.n_envs, 4, 8, self.layout.height, self.layout.width)), None
+
+    def close(self):
+        pass
+
+
+def _trainer_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from pmx import trainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    N, T = 6, 4
+    tr = trainer.VecMAPPOTrainer("tinyCapture", N, horizon=T, minibatch=16, device="cpu", seed=3, rank=rank, world_size=world,
+                                 process_group=dist.group.WORLD, use_autocast=False, opponent="curriculum", curriculum_scale=0.005,
+                                 total_updates=50, env=_StubEnv("tinyCapture", N))
+    g = torch.Generator().manual_seed(100 + rank)                 # every rank has its OWN rollout data
+    modes = []
+    for u in range(3):
+        tr.update_idx = (0, 3, 7)[u]                               # one update in each curriculum phase (thresholds 1 and 4)
+        modes.append(tr._pick_opponent())
+        tr.obs_buf.copy_((torch.rand(tr.obs_buf.shape, generator=g) < 0.2).float())
+        tr.merged_buf.copy_((torch.rand(tr.merged_buf.shape, generator=g) < 0.2).float())
+        tr.act_buf.copy_(torch.randint(0, 5, tr.act_buf.shape, generator=g))
+        tr.logp_buf.copy_(-1.6 + 0.1 * torch.randn(tr.logp_buf.shape, generator=g))
+        tr.adv_buf.copy_(torch.randn(tr.adv_buf.shape, generator=g))
+        tr.ret_buf.copy_(torch.randn(tr.ret_buf.shape, generator=g))
+        tr.update()
+    q.put((rank, modes, tr.learner.bucket.data.clone().numpy(), tr.learner.ema.clone().numpy(), int(tr.stats["optimizer_steps"])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_update_two_ranks_gloo_same_modes_same_weights():
+    """VecMAPPOTrainer.update under torch.distributed (gloo, 2 ranks, CPU tensors, different data per rank): the opponent
+    mode / side sequence of the curriculum is the same on every rank (it must be: a rank that plays self-play does an extra
+    forward per tick while the others wait at the all-reduce) and the weights and the EMA stay bit-identical."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = {}
+    for _ in range(2):
+        r, modes, data, ema, steps = q.get(timeout=600)
+        res[r] = (modes, data, ema, steps)
+    for p in procs: p.join(60)
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    assert res[0][0][0][0] == "random" and res[0][0][1][0] in ("random", "baseline") and res[0][0][2][0] in ("self", "pool", "random", "baseline")
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    assert res[0][3] == res[1][3] == 3 * (4 * 6 * 2 // 16)
+
+
+def test_curriculum_phases_and_pool_draws_on_the_host():
+    """_pick_opponent (pacman_mappo_resnet.py:396-438): randomTeam only in the first phase, randomTeam / baselineTeam in the
+    second, self-play / pool / bots with both colours in the third; the pool grows every OPPONENT_UPDATE_FREQ updates."""
+    from pmx import trainer
+    tr = trainer.VecMAPPOTrainer("tinyCapture", 4, horizon=2, minibatch=8, device="cpu", seed=1, use_autocast=False,
+                                 opponent="curriculum", curriculum_scale=0.1, env=_StubEnv("tinyCapture", 4))
+    seen = {1: set(), 2: set(), 3: set()}
+    sides = set()
+    for phase, idx in ((1, 10), (2, 50), (3, 200)):
+        for _ in range(200):
+            tr.update_idx = idx
+            mode, red = tr._pick_opponent()
+            seen[phase].add(mode)
+            if mode in ("self", "pool"):
+                sides.add(red)
+            else:
+                assert red is False
+    assert seen[1] == {"random"} and seen[2] == {"random", "baseline"} and seen[3] == {"self", "pool", "random", "baseline"}
+    assert sides == {True, False}
+    n0 = len(tr.opponent_pool)
+    for k, v in (("obs_buf", 0.0), ("merged_buf", 0.0)):
+        getattr(tr, k).fill_(v)
+    tr.adv_buf.normal_(); tr.ret_buf.normal_(); tr.logp_buf.fill_(-1.6)
+    tr.update_idx = 0
+    tr.update()                                                    # update 0 is a multiple of the snapshot frequency
+    assert len(tr.opponent_pool) == n0 + 1 and tr.update_idx == 1
+    tr.opponent_mode = "pool"
+    mode, _ = tr._pick_opponent()
+    assert mode == "pool"
+    sd = tr.opponent_model.state_dict()
+    assert any(all(torch.equal(sd[k], snap[k]) for k in snap) for snap in tr.opponent_pool)
+
+
+def test_full_checkpoint_round_trip_continues_identically(tmp_path):
+    """save_full -> load_full into a fresh trainer: the next update (same rollout buffers) gives bit-identical weights,
+    moments, EMA, pool and random draws; the file loads with weights_only=True (tensors and numbers only)."""
+    from pmx import trainer
+
+    def make():
+        return trainer.VecMAPPOTrainer("tinyCapture", 4, horizon=3, minibatch=8, device="cpu", seed=2, use_autocast=False,
+                                       opponent="pool", total_updates=40, env=_StubEnv("tinyCapture", 4))
+
+    def fill(tr, seed):
+        g = torch.Generator().manual_seed(seed)
+        tr.obs_buf.copy_((torch.rand(tr.obs_buf.shape, generator=g) < 0.2).float())
+        tr.merged_buf.copy_((torch.rand(tr.merged_buf.shape, generator=g) < 0.2).float())
+        tr.act_buf.copy_(torch.randint(0, 5, tr.act_buf.shape, generator=g))
+        tr.logp_buf.copy_(-1.6 + 0.1 * torch.randn(tr.logp_buf.shape, generator=g))
+        tr.adv_buf.copy_(torch.randn(tr.adv_buf.shape, generator=g)); tr.ret_buf.copy_(torch.randn(tr.ret_buf.shape, generator=g))
+    a = make()
+    fill(a, 1); a.update(); a._pick_opponent()
+    path = str(tmp_path / "full.pt")
+    a.save_full(path)
+    torch.load(path, weights_only=True)                            # nothing in the file needs the unpickler
+    b = make()
+    b.load_full(path)
+    assert b.update_idx == a.update_idx == 1 and b.learner.step_count == a.learner.step_count
+    for tr in (a, b):
+        fill(tr, 2); tr.update()
+    for x, y in ((a.learner.bucket.data, b.learner.bucket.data), (a.learner.ema, b.learner.ema),
+                 (a.learner.exp_avg, b.learner.exp_avg), (a.learner.exp_avg_sq, b.learner.exp_avg_sq)):
+        assert torch.equal(x, y)
+    assert [a._pick_opponent() for _ in range(5)] == [b._pick_opponent() for _ in range(5)]
+    assert len(a.opponent_pool) == len(b.opponent_pool)
+    c = trainer.VecMAPPOTrainer("tinyCapture", 4, horizon=3, minibatch=8, device="cpu", seed=2, use_autocast=False,
+                                total_updates=41, env=_StubEnv("tinyCapture", 4))
+    with pytest.raises(ValueError):
+        c.load_full(path)                                          # another schedule length: refuse
+
+
+def test_ema_checkpoint_loads_into_a_fresh_agent(tmp_path):
+    """save_ema writes what the reference saves (pacman_mappo_resnet.py:647-651): a state_dict of the EMA weights with the
+    reference's parameter names, loadable into a fresh MAPPOAgent."""
+    from pmx import mappo, trainer
+    tr = trainer.VecMAPPOTrainer("tinyCapture", 4, horizon=2, minibatch=8, device="cpu", seed=4, use_autocast=False,
+                                 env=_StubEnv("tinyCapture", 4))
+    tr.adv_buf.normal_(); tr.ret_buf.normal_(); tr.logp_buf.fill_(-1.6)
+    tr.update()
+    path = str(tmp_path / "ema.pt")
+    tr.save_ema(path)
+    sd = torch.load(path, weights_only=True)
+    fresh = mappo.MAPPOAgent(tr.obs_shape, 5, 2)
+    fresh.load_state_dict(sd, strict=True)
+    flat = torch.cat([p.detach().reshape(-1) for p in fresh.parameters()])
+    assert torch.equal(flat, tr.learner.ema)
+    assert not torch.equal(flat, tr.learner.bucket.data)           # one step at EMA 0.995: the EMA lags the weights

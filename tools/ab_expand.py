@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """In-process A/B of expansion-kernel launch options (cdna_hip_programming.md rule 24: interleaved rounds, one process).
-    python tools/ab_expand.py --envs 16384 --obs float32 --var PMX_EXPAND_NT --values 0,1"""
+    python tools/ab_expand.py --envs 16384 --obs float32 --var expand_nt --values 0,1      (keys of pmx_set_tuning)"""
 import argparse, os, statistics, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +10,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--envs", type=int, default=16384)
 ap.add_argument("--obs", default="float32")
 ap.add_argument("--layout", default="smallCapture")
-ap.add_argument("--var", default="PMX_EXPAND_NT")
+ap.add_argument("--var", default="expand_nt")
 ap.add_argument("--values", default="0,1")
 ap.add_argument("--rounds", type=int, default=12)
 ap.add_argument("--ticks", type=int, default=100)
@@ -24,7 +24,7 @@ res = {v: [] for v in vals}
 tick = {v: [] for v in vals}
 for r in range(a.rounds):
     for v in vals:
-        os.environ[a.var] = v
+        env.set_tuning(a.var, int(v))
         for k in range(10):
             env.step(acts[k % 32])
         torch.cuda.synchronize()
