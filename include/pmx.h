@@ -273,6 +273,19 @@ int pmx_actor_backward(const void *obs_dev, int32_t obs_dtype, const void *pack_
 /* grad_dev -> float32 gradients in the parameters' own shapes (the pointers of `out` are written, not read) */
 int pmx_actor_unpack_grads(const float *grad_dev, const pmx_actor_params *out, void *stream);
 
+/* ---- The feed-forward half of the critic's encoder layer as one forward and one backward kernel ----------------------
+ * nn.TransformerEncoderLayer(d_model 32, dim_feedforward 128, ReLU, dropout 0, norm_first False), pacman_mappo_resnet.py:138-141:
+ *   y = LayerNorm(x + linear2(relu(linear1(x))))   on [tokens][32] bfloat16 rows, fp32 accumulation and LayerNorm.
+ * Parameters are float32 device pointers with nn.Module shapes (linear1.weight [128][32], linear2.weight [32][128], norm2). */
+#define PMX_FFN_PACK_BYTES 33664
+#define PMX_FFN_GRAD_FLOATS 8416      /* dW2 [32][128], dW1 [128][32], db1 [128], db2 [32], dgamma [32], dbeta [32] */
+int pmx_ffn_pack(const float *w1, const float *b1, const float *w2, const float *b2, const float *gamma, const float *beta,
+                 void *pack_dev, void *stream);
+int pmx_ffn_forward(const void *x_dev, const void *pack_dev, void *y_dev, int64_t tokens, float eps, void *stream);
+/* recomputes the forward from x (nothing is saved): dx_dev [tokens][32] bfloat16, grad_dev [PMX_FFN_GRAD_FLOATS] zeroed and summed here */
+int pmx_ffn_backward(const void *x_dev, const void *dy_dev, const void *pack_dev, void *dx_dev, float *grad_dev, int64_t tokens,
+                     float eps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,8 @@ COLSUM_BLOCKS = 512
 LN32_PARTIAL_ROWS = 2048
 ACTOR_PACK_BYTES = 297984
 ACTOR_GRAD_FLOATS = 74496
+FFN_PACK_BYTES = 33664
+FFN_GRAD_FLOATS = 8416
 
 
 class PmxError(RuntimeError):
@@ -84,6 +86,9 @@ PROTOTYPES = [
     ("pmx_actor_forward", C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, C.c_int64, _I32, _I32, _VP]),
     ("pmx_actor_backward", C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, _VP, C.c_int64, _I32, _I32, _VP]),
     ("pmx_actor_unpack_grads", C.c_int, [_VP, C.POINTER(ActorParams), _VP]),
+    ("pmx_ffn_pack", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    ("pmx_ffn_forward", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_float, _VP]),
+    ("pmx_ffn_backward", C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_float, _VP]),
 ]
 # test / bench hooks that are not part of the public header
 EXTRA = [

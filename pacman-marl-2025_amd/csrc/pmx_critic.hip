@@ -1,0 +1,450 @@
+// pmx_critic.hip -- the feed-forward half of the critic's post-LN encoder layer (nn.TransformerEncoderLayer with d_model 32,
+// dim_feedforward 128, ReLU, dropout 0; pacman_mappo_resnet.py:126-141) as ONE forward and ONE backward kernel:
+//     y = LayerNorm(x + W2 relu(W1 x + b1) + b2)
+// on [tokens][32] bf16 rows.  Tokens are independent, so a wavefront owns tiles of 16 tokens and keeps everything in
+// registers: every product is a v_mfma_f32_16x16x32_bf16 with the FEATURES on the rows and the TOKENS on the columns
+// (D[feature][token] = A[feature][k] x B[k][token]); the B operand of the first product is one 16-byte load per lane from
+// the token row, and the accumulators of one product, converted to bf16, ARE the B operand of the next one -- the
+// contraction index may be enumerated in any order as long as the A operand (the weights, pre-packed) uses the same one:
+//     hidden order   phi(s, g, j) = 32 s + 16 (j >> 2) + 4 g + (j & 3)     k-step s, lane group g = lane >> 4, element j
+//     output order   psi(m, g, r) = 8 g + 4 m + r                         so that a lane ends up with features 8g .. 8g+7,
+// exactly the ones it loaded -- the residual add, LayerNorm (8 values per lane + 2 shuffles over the 4 lane groups of a
+// token) and the 16-byte store are lane-local.  No LDS in the forward kernel, the hidden activations never exist in memory.
+//
+// Backward recomputes the forward from x (nothing is saved), runs LayerNorm's and the two products' input gradients the same
+// way (dH = W2^T dF, dX = W1^T dH + dz) and forms the weight gradients -- contractions over TOKENS -- from a 32-token
+// staging area in LDS read back through ds_read_b64_tr_b16; their 32 output tiles (128 accumulator registers) stay in
+// registers across all tiles of the wave and leave through one block-level LDS sum + float atomics.
+#pragma clang fp contract(fast)
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+#include "../../include/pmx.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+// packed-parameter buffer (bytes)
+constexpr int FRAG = 64 * 8;                                 // bf16 elements of one operand fragment
+constexpr size_t P_A1 = 0;                                   // W1 forward     [8 hidden tiles]
+constexpr size_t P_A2 = P_A1 + 8 * FRAG * 2;                 // W2 forward     [2 output halves][4 k-steps]
+constexpr size_t P_A3 = P_A2 + 8 * FRAG * 2;                 // W2^T           [8 hidden tiles]
+constexpr size_t P_A4 = P_A3 + 8 * FRAG * 2;                 // W1^T           [2 input halves][4 k-steps]
+constexpr size_t P_B1 = P_A4 + 8 * FRAG * 2;                 // float b1[128], b2[32], gamma[32], beta[32]
+constexpr size_t P_BYTES = P_B1 + (128 + 32 + 32 + 32) * 4;
+static_assert(P_BYTES == PMX_FFN_PACK_BYTES, "include/pmx.h and pmx_critic.hip disagree on the pack size");
+// gradient buffer (floats): dW2 [32][128], dW1 [128][32], db1 [128], db2 [32], dgamma [32], dbeta [32]
+constexpr int G_W2 = 0, G_W1 = G_W2 + 32 * 128, G_B1 = G_W1 + 128 * 32, G_B2 = G_B1 + 128, G_GAMMA = G_B2 + 32, G_BETA = G_GAMMA + 32;
+constexpr int G_FLOATS = G_BETA + 32;
+static_assert(G_FLOATS == PMX_FFN_GRAD_FLOATS, "include/pmx.h and pmx_critic.hip disagree on the gradient size");
+
+__device__ __forceinline__ uint32_t pack2(float a, float b)
+{
+    f32x2 f = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
+}
+__device__ __forceinline__ float lo_f(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float hi_f(uint32_t u) { return __uint_as_float(u & 0xFFFF0000u); }
+
+__device__ __forceinline__ bf16x8 frag_of(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    const uint4 u = {a, b, c, d};
+    return __builtin_bit_cast(bf16x8, u);
+}
+
+// sum over the four lane groups that hold one token's 32 features
+__device__ __forceinline__ float token_sum(float v)
+{
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+// sum over the 16 tokens of a tile (lanes with the same g)
+__device__ __forceinline__ float tile_sum(float v)
+{
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+struct Weights {
+    bf16x8 A1[8];        // W1 forward
+    bf16x8 A2[2][4];     // W2 forward
+};
+
+__device__ __forceinline__ void load_fwd_weights(Weights &w, const char *pack, int lane)
+{
+    const bf16x8 *a1 = reinterpret_cast<const bf16x8 *>(pack + P_A1), *a2 = reinterpret_cast<const bf16x8 *>(pack + P_A2);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) w.A1[m] = a1[m * 64 + lane];
+#pragma unroll
+    for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) w.A2[mo][s] = a2[(mo * 4 + s) * 64 + lane];
+}
+
+// The forward chain for one tile: xb = the lane's 8 input features (bf16 pairs).  Leaves relu(H) in hr (bf16 pairs, operand
+// order), z = x + F + b2 in z[8] (true features 8g + j).
+__device__ __forceinline__ void ffn_tile(const Weights &w, const uint4 xb, const float (&b1)[8][4], const float (&b2)[8], uint32_t (&hr)[8][2],
+                                         float (&z)[8])
+{
+    const bf16x8 B0 = __builtin_bit_cast(bf16x8, xb);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        f32x4 c = {b1[m][0], b1[m][1], b1[m][2], b1[m][3]};
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.A1[m], B0, c, 0, 0, 0);
+        hr[m][0] = pack2(fmaxf(c[0], 0.f), fmaxf(c[1], 0.f));
+        hr[m][1] = pack2(fmaxf(c[2], 0.f), fmaxf(c[3], 0.f));
+    }
+    f32x4 f0 = {b2[0], b2[1], b2[2], b2[3]}, f1 = {b2[4], b2[5], b2[6], b2[7]};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const bf16x8 B1 = frag_of(hr[2 * s][0], hr[2 * s][1], hr[2 * s + 1][0], hr[2 * s + 1][1]);
+        f0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.A2[0][s], B1, f0, 0, 0, 0);
+        f1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.A2[1][s], B1, f1, 0, 0, 0);
+    }
+    const float x[8] = {lo_f(xb.x), hi_f(xb.x), lo_f(xb.y), hi_f(xb.y), lo_f(xb.z), hi_f(xb.z), lo_f(xb.w), hi_f(xb.w)};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) z[r] = x[r] + f0[r], z[4 + r] = x[4 + r] + f1[r];
+}
+
+__device__ __forceinline__ void load_small_params(const char *pack, int g, float (&b1)[8][4], float (&b2)[8], float (&gamma)[8], float (&beta)[8])
+{
+    const float *pb = reinterpret_cast<const float *>(pack + P_B1);
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b1[m][r] = pb[16 * m + 4 * g + r];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b2[j] = pb[128 + 8 * g + j], gamma[j] = pb[160 + 8 * g + j], beta[j] = pb[192 + 8 * g + j];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void pmx_ffn_fwd_kernel(const uint4 *__restrict__ x, const char *__restrict__ pack, uint4 *__restrict__ y,
+                                                            long T, float eps)
+{
+    const int lane = threadIdx.x & 63, p = lane & 15, g = lane >> 4;
+    const long n_tiles = (T + 15) >> 4;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (long)gridDim.x * 4;
+    Weights w;
+    load_fwd_weights(w, pack, lane);
+    float b1[8][4], b2[8], gamma[8], beta[8];
+    load_small_params(pack, g, b1, b2, gamma, beta);
+    // two tiles in flight ahead of the one being computed
+    auto fetch = [&](long tile) -> uint4 {
+        const long tok = tile * 16 + p;
+        return (tile < n_tiles && tok < T) ? x[tok * 4 + g] : uint4{0, 0, 0, 0};
+    };
+    uint4 x0 = fetch(wave), x1 = fetch(wave + n_waves);
+    for (long tile = wave; tile < n_tiles; tile += n_waves) {
+        const uint4 x2 = fetch(tile + 2 * n_waves);
+        uint32_t hr[8][2];
+        float z[8];
+        ffn_tile(w, x0, b1, b2, hr, z);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s1 += z[j];
+        const float mean = token_sum(s1) * (1.0f / 32.0f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            z[j] -= mean;
+            s2 = fmaf(z[j], z[j], s2);
+        }
+        const float rstd = __builtin_amdgcn_rsqf(token_sum(s2) * (1.0f / 32.0f) + eps);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fmaf(z[j] * rstd, gamma[j], beta[j]);
+        const long tok = tile * 16 + p;
+        if (tok < T) y[tok * 4 + g] = uint4{pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
+        x0 = x1, x1 = x2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward.  One wave per SIMD (the weight-gradient accumulators and four operand sets leave no room for two).
+// LDS per wave: a 32-token staging area [token][x 32 | dF 32 | H 128 | dH 128] bf16 = 640 bytes per token.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int STG_ROW = 320 * 2 + 16;          // bytes per staged token (+16: rows 4 banks apart instead of aligned)
+constexpr int STG_X = 0, STG_DF = 64, STG_H = 128, STG_DH = 384;
+
+__device__ __forceinline__ bf16x8 tr_frag(const char *stg, int col_byte, int lane)
+{
+    // operand fragment for a contraction over the 32 staged tokens: lane group g covers tokens 8g .. 8g+7, columns
+    // col_byte/2 .. +15; lane 4*row + pc of the group addresses token row, columns 4*pc .. 4*pc+3
+    const int g = lane >> 4, row = (lane & 15) >> 2, pc = lane & 3;
+    const char *a0 = stg + (8 * g + row) * STG_ROW + col_byte + pc * 8;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)(a0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)(a0 + 4 * STG_ROW));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__global__ __launch_bounds__(256, 1) void pmx_ffn_bwd_kernel(const uint4 *__restrict__ x, const uint4 *__restrict__ dy, const char *__restrict__ pack,
+                                                            uint4 *__restrict__ dx, float *__restrict__ grad, long T, float eps)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, p = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    char *stg = smem + (size_t)wv * 32 * STG_ROW;
+    const long n_pairs = (T + 31) >> 5;
+    const long wave = (long)blockIdx.x * 4 + wv, n_waves = (long)gridDim.x * 4;
+    Weights w;
+    load_fwd_weights(w, pack, lane);
+    bf16x8 A3[8], A4[2][4];
+    {
+        const bf16x8 *a3 = reinterpret_cast<const bf16x8 *>(pack + P_A3), *a4 = reinterpret_cast<const bf16x8 *>(pack + P_A4);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) A3[m] = a3[m * 64 + lane];
+#pragma unroll
+        for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) A4[mo][s] = a4[(mo * 4 + s) * 64 + lane];
+    }
+    float b1[8][4], b2[8], gamma[8], beta[8];
+    load_small_params(pack, g, b1, b2, gamma, beta);
+    f32x4 aw2[2][8], aw1[8][2];                  // dW2 tiles [out half][hidden tile], dW1 tiles [hidden tile][in half]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) aw2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}, aw1[b][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float db1[8][4], db2[8], dgam[8], dbet[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) db1[m][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) db2[j] = dgam[j] = dbet[j] = 0.f;
+
+    auto fetch = [&](const uint4 *src, long pair, int u) -> uint4 {
+        const long tok = pair * 32 + 16 * u + p;
+        return (pair < n_pairs && tok < T) ? src[tok * 4 + g] : uint4{0, 0, 0, 0};
+    };
+    uint4 xn[2] = {fetch(x, wave, 0), fetch(x, wave, 1)}, dn[2] = {fetch(dy, wave, 0), fetch(dy, wave, 1)};
+    for (long pair = wave; pair < n_pairs; pair += n_waves) {
+        const uint4 xc[2] = {xn[0], xn[1]}, dc[2] = {dn[0], dn[1]};
+        xn[0] = fetch(x, pair + n_waves, 0), xn[1] = fetch(x, pair + n_waves, 1);
+        dn[0] = fetch(dy, pair + n_waves, 0), dn[1] = fetch(dy, pair + n_waves, 1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            uint32_t hr[8][2];
+            float z[8];
+            ffn_tile(w, xc[u], b1, b2, hr, z);
+            // LayerNorm forward statistics, then its backward
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s1 += z[j];
+            const float mean = token_sum(s1) * (1.0f / 32.0f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                z[j] -= mean;
+                s2 = fmaf(z[j], z[j], s2);
+            }
+            const float rstd = __builtin_amdgcn_rsqf(token_sum(s2) * (1.0f / 32.0f) + eps);
+            const float d[8] = {lo_f(dc[u].x), hi_f(dc[u].x), lo_f(dc[u].y), hi_f(dc[u].y), lo_f(dc[u].z), hi_f(dc[u].z), lo_f(dc[u].w), hi_f(dc[u].w)};
+            float gd[8], t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = z[j] * rstd;
+                z[j] = xh;
+                dbet[j] += d[j];
+                dgam[j] = fmaf(d[j], xh, dgam[j]);
+                gd[j] = gamma[j] * d[j];
+                t1 += gd[j];
+                t2 = fmaf(gd[j], xh, t2);
+            }
+            t1 = token_sum(t1) * (1.0f / 32.0f), t2 = token_sum(t2) * (1.0f / 32.0f);
+            float dz[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dz[j] = rstd * (gd[j] - t1 - z[j] * t2);
+            const uint4 dzb = {pack2(dz[0], dz[1]), pack2(dz[2], dz[3]), pack2(dz[4], dz[5]), pack2(dz[6], dz[7])};
+            {   // the bias gradient of the second product sums what the matrix cores see
+                const float q[8] = {lo_f(dzb.x), hi_f(dzb.x), lo_f(dzb.y), hi_f(dzb.y), lo_f(dzb.z), hi_f(dzb.z), lo_f(dzb.w), hi_f(dzb.w)};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) db2[j] += q[j];
+            }
+            // dH = W2^T dF, masked by relu'(H); dX = W1^T dH + dz
+            const bf16x8 Bd = __builtin_bit_cast(bf16x8, dzb);
+            uint32_t dh[8][2];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A3[m], Bd, c, 0, 0, 0);
+                const float h0 = lo_f(hr[m][0]), h1 = hi_f(hr[m][0]), h2 = lo_f(hr[m][1]), h3 = hi_f(hr[m][1]);
+                const float c0 = h0 > 0.f ? c[0] : 0.f, c1 = h1 > 0.f ? c[1] : 0.f, c2 = h2 > 0.f ? c[2] : 0.f, c3 = h3 > 0.f ? c[3] : 0.f;
+                dh[m][0] = pack2(c0, c1), dh[m][1] = pack2(c2, c3);
+                db1[m][0] += lo_f(dh[m][0]), db1[m][1] += hi_f(dh[m][0]), db1[m][2] += lo_f(dh[m][1]), db1[m][3] += hi_f(dh[m][1]);
+            }
+            f32x4 e0 = {dz[0], dz[1], dz[2], dz[3]}, e1 = {dz[4], dz[5], dz[6], dz[7]};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 Bh = frag_of(dh[2 * s][0], dh[2 * s][1], dh[2 * s + 1][0], dh[2 * s + 1][1]);
+                e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A4[0][s], Bh, e0, 0, 0, 0);
+                e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A4[1][s], Bh, e1, 0, 0, 0);
+            }
+            const long tok = pair * 32 + 16 * u + p;
+            if (tok < T) dx[tok * 4 + g] = uint4{pack2(e0[0], e0[1]), pack2(e0[2], e0[3]), pack2(e1[0], e1[1]), pack2(e1[2], e1[3])};
+            // stage this tile's operands of the weight gradients: [token][x | dF | H | dH]
+            char *row = stg + (16 * u + p) * STG_ROW;
+            *reinterpret_cast<uint4 *>(row + STG_X + 16 * g) = xc[u];
+            *reinterpret_cast<uint4 *>(row + STG_DF + 16 * g) = dzb;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                *reinterpret_cast<uint2 *>(row + STG_H + 32 * m + 8 * g) = uint2{hr[m][0], hr[m][1]};
+                *reinterpret_cast<uint2 *>(row + STG_DH + 32 * m + 8 * g) = uint2{dh[m][0], dh[m][1]};
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // weight gradients over the pair's 32 tokens
+        bf16x8 Fx[2], Fd[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) Fx[a] = tr_frag(stg, STG_X + 32 * a, lane), Fd[a] = tr_frag(stg, STG_DF + 32 * a, lane);
+#pragma unroll
+        for (int mh = 0; mh < 8; ++mh) {
+            const bf16x8 Fh = tr_frag(stg, STG_H + 32 * mh, lane), Fdh = tr_frag(stg, STG_DH + 32 * mh, lane);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                aw2[a][mh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fd[a], Fh, aw2[a][mh], 0, 0, 0);     // dW2[out][hidden] += dF^T H
+                aw1[mh][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fdh, Fx[a], aw1[mh][a], 0, 0, 0);    // dW1[hidden][in] += dH^T x
+            }
+        }
+    }
+    // ---- reductions: block-level sum of the 32 weight-gradient tiles through LDS, per-channel sums through shuffles ----
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem);           // 4 waves x 8 tiles x 1 KB = 32 KB per round (the staging areas are 80 KB)
+#pragma unroll
+    for (int round = 0; round < 4; ++round) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 v = round < 2 ? aw2[round][i] : aw1[i][round - 2];
+            *reinterpret_cast<f32x4 *>(red + ((size_t)(wv * 8 + i) * 64 + lane) * 4) = v;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 8 * 64; i += 256) {
+            f32x4 v = *reinterpret_cast<const f32x4 *>(red + (size_t)i * 4);
+#pragma unroll
+            for (int q = 1; q < 4; ++q) {
+                const f32x4 u = *reinterpret_cast<const f32x4 *>(red + ((size_t)q * 8 * 64 + i) * 4);
+                v[0] += u[0], v[1] += u[1], v[2] += u[2], v[3] += u[3];
+            }
+            // tile i of this round, lane l, register r: D[row = 4 (l >> 4) + r][col = l & 15]
+            const int t = i >> 6, l = i & 63, rg = l >> 4, col = l & 15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rowi = 4 * rg + r;
+                float *dst = round < 2 ? grad + G_W2 + (16 * round + rowi) * 128 + 16 * t + col          // dW2[out][hidden]
+                                       : grad + G_W1 + (16 * t + rowi) * 32 + 16 * (round - 2) + col;    // dW1[hidden][in]
+                if (v[r] != 0.f) atomicAdd(dst, v[r]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = tile_sum(db1[m][r]);
+            if (p == 0 && v != 0.f) atomicAdd(grad + G_B1 + 16 * m + 4 * g + r, v);
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float a = tile_sum(db2[j]), b = tile_sum(dgam[j]), c = tile_sum(dbet[j]);
+        if (p == 0) {
+            if (a != 0.f) atomicAdd(grad + G_B2 + 8 * g + j, a);
+            if (b != 0.f) atomicAdd(grad + G_GAMMA + 8 * g + j, b);
+            if (c != 0.f) atomicAdd(grad + G_BETA + 8 * g + j, c);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// float32 parameters -> operand fragments.  hidden order phi, output / input order psi (file header).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pmx_ffn_pack_kernel(const float *__restrict__ w1, const float *__restrict__ b1, const float *__restrict__ w2,
+                                                          const float *__restrict__ b2, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                          char *__restrict__ pack)
+{
+    // w1 [128][32] (linear1.weight), w2 [32][128] (linear2.weight)
+    short *a1 = reinterpret_cast<short *>(pack + P_A1), *a2 = reinterpret_cast<short *>(pack + P_A2);
+    short *a3 = reinterpret_cast<short *>(pack + P_A3), *a4 = reinterpret_cast<short *>(pack + P_A4);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 8 * FRAG; i += gridDim.x * 256) {
+        const int j = i & 7, lane = (i >> 3) & 63, f = i >> 9;          // fragment f, lane, element j
+        const int row = lane & 15, g = lane >> 4;
+        const int psi_row = 8 * (row >> 2) + (row & 3);                 // + 4 * half
+        auto phi = [&](int s) { return 32 * s + 16 * (j >> 2) + 4 * g + (j & 3); };
+        // A1[m = f]: W1[hidden 16 m + row][in 8 g + j]
+        a1[i] = (short)(pack2(w1[(16 * f + row) * 32 + 8 * g + j], 0.f) & 0xFFFF);
+        // A2[mo][s], f = mo * 4 + s: W2[out psi(mo, row)][hidden phi(s, g, j)]
+        a2[i] = (short)(pack2(w2[(psi_row + 4 * (f >> 2)) * 128 + phi(f & 3)], 0.f) & 0xFFFF);
+        // A3[m = f]: W2[out 8 g + j][hidden 16 m + row]      (dH = W2^T dF)
+        a3[i] = (short)(pack2(w2[(8 * g + j) * 128 + 16 * f + row], 0.f) & 0xFFFF);
+        // A4[mo][s]: W1[hidden phi(s, g, j)][in psi(mo, row)]  (dX = W1^T dH)
+        a4[i] = (short)(pack2(w1[phi(f & 3) * 32 + psi_row + 4 * (f >> 2)], 0.f) & 0xFFFF);
+    }
+    if (blockIdx.x == 0) {
+        float *pb = reinterpret_cast<float *>(pack + P_B1);
+        for (int i = threadIdx.x; i < 128; i += 256) pb[i] = b1[i];
+        if (threadIdx.x < 32) pb[128 + threadIdx.x] = b2[threadIdx.x], pb[160 + threadIdx.x] = gamma[threadIdx.x], pb[192 + threadIdx.x] = beta[threadIdx.x];
+    }
+}
+
+int cu_count()
+{
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    return cus;
+}
+
+}   // namespace
+
+extern "C" int pmx_ffn_pack(const float *w1, const float *b1, const float *w2, const float *b2, const float *gamma, const float *beta,
+                            void *pack_dev, void *stream)
+{
+    if (!w1 || !b1 || !w2 || !b2 || !gamma || !beta || !pack_dev) return PMX_ERR_INVALID;
+    hipLaunchKernelGGL(pmx_ffn_pack_kernel, dim3(16), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w1, b1, w2, b2, gamma, beta,
+                       reinterpret_cast<char *>(pack_dev));
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
+
+extern "C" int pmx_ffn_forward(const void *x_dev, const void *pack_dev, void *y_dev, int64_t tokens, float eps, void *stream)
+{
+    if (tokens == 0) return PMX_OK;
+    if (!x_dev || !pack_dev || !y_dev || tokens < 0) return PMX_ERR_INVALID;
+    const int64_t tiles = (tokens + 15) / 16;
+    const int64_t want = (tiles + 3) / 4, cap = (int64_t)cu_count() * 2;
+    hipLaunchKernelGGL(pmx_ffn_fwd_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       (const uint4 *)x_dev, (const char *)pack_dev, (uint4 *)y_dev, (long)tokens, eps);
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
+
+extern "C" int pmx_ffn_backward(const void *x_dev, const void *dy_dev, const void *pack_dev, void *dx_dev, float *grad_dev, int64_t tokens,
+                                float eps, void *stream)
+{
+    if (!grad_dev) return PMX_ERR_INVALID;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(grad_dev, 0, sizeof(float) * G_FLOATS, st) != hipSuccess) return PMX_ERR_HIP;
+    if (tokens == 0) return PMX_OK;
+    if (!x_dev || !dy_dev || !pack_dev || !dx_dev || tokens < 0) return PMX_ERR_INVALID;
+    const size_t lds = (size_t)4 * 32 * STG_ROW;
+    static bool attr_dev[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PMX_ERR_HIP;
+    if (lds > 65536 && !attr_dev[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(pmx_ffn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return PMX_ERR_HIP;
+        attr_dev[dev] = true;
+    }
+    const int64_t pairs = (tokens + 31) / 32;
+    const int64_t want = (pairs + 3) / 4, cap = (int64_t)cu_count();
+    hipLaunchKernelGGL(pmx_ffn_bwd_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(256), lds, st, (const uint4 *)x_dev, (const uint4 *)dy_dev,
+                       (const char *)pack_dev, (uint4 *)dx_dev, grad_dev, (long)tokens, eps);
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}

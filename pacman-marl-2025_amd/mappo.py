@@ -80,6 +80,57 @@ def add_layer_norm_small(x, a, ln):
     return layer_norm_small(x + a, ln)
 
 
+class _FFNLayerNorm(torch.autograd.Function):
+    """LayerNorm(x + linear2(relu(linear1(x)))) on [..., 32] bfloat16 tokens through pmx_ffn_forward / pmx_ffn_backward
+    (csrc/pmx_critic.hip): one kernel each way, the 128-wide hidden activations never reach memory, backward recomputes."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        x = x.contiguous()
+        dev = x.device
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        ps = [t.detach().float().contiguous() for t in (w1, b1, w2, b2, gamma, beta)]
+        pack = torch.empty(_lib.FFN_PACK_BYTES, dtype=torch.uint8, device=dev)
+        _lib.check(lib.pmx_ffn_pack(*[t.data_ptr() for t in ps], pack.data_ptr(), st), "pmx_ffn_pack")
+        y = torch.empty_like(x)
+        _lib.check(lib.pmx_ffn_forward(x.data_ptr(), pack.data_ptr(), y.data_ptr(), x.numel() // 32, float(eps), st), "pmx_ffn_forward")
+        ctx.save_for_backward(x, pack)
+        ctx.eps = float(eps)
+        ctx.dtypes = [t.dtype for t in (w1, b1, w2, b2, gamma, beta)]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        x, pack = ctx.saved_tensors
+        dev = x.device
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        dy = dy.to(torch.bfloat16).contiguous()
+        dx = torch.empty_like(x)
+        grad = torch.empty(_lib.FFN_GRAD_FLOATS, dtype=torch.float32, device=dev)
+        _lib.check(lib.pmx_ffn_backward(x.data_ptr(), dy.data_ptr(), pack.data_ptr(), dx.data_ptr(), grad.data_ptr(), x.numel() // 32,
+                                        ctx.eps, st), "pmx_ffn_backward")
+        dw2, dw1 = grad[:4096].view(32, 128), grad[4096:8192].view(128, 32)
+        db1, db2, dg, dbeta = grad[8192:8320], grad[8320:8352], grad[8352:8384], grad[8384:8416]
+        outs = (dw1, db1, dw2, db2, dg, dbeta)
+        return (dx,) + tuple(o.to(dt) for o, dt in zip(outs, ctx.dtypes)) + (None,)
+
+
+def ffn_layer_norm(x, lin1, lin2, ln):
+    """The feed-forward half of the post-LN encoder layer: the fused HIP kernels for bf16 tokens of width 32 with a 128-wide
+    hidden layer on the GPU, the separate ops otherwise."""
+    if (x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] == 32 and tuple(lin1.weight.shape) == (128, 32)
+            and tuple(lin2.weight.shape) == (32, 128) and lin1.weight.dtype == torch.float32 and MAPPOAgent.fused_ffn):
+        return _FFNLayerNorm.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias, ln.weight, ln.bias, ln.eps)
+    f = token_linear(F.relu(token_linear(x, lin1.weight, lin1.bias)), lin2.weight, lin2.bias)
+    return add_layer_norm_small(x, f, ln)
+
+
 def attention8_forward(qkv, want_lse=False):
     """softmax(q k^T / sqrt(8)) v for 4 heads of 8 on the matrix cores (pmx_attn8_forward): qkv [S, B, 96] bfloat16 ->
     [S, B, 32] bfloat16 (+ log-sum-exp [B, 4, S] float32)."""
@@ -189,8 +240,7 @@ class CriticEncoderLayer(nn.TransformerEncoderLayer):
             a = attention8(qkv) if torch.is_grad_enabled() else attention8_forward(qkv)   # hand-written MFMA attention
             a = token_linear(a, mha.out_proj.weight, mha.out_proj.bias)
             x = add_layer_norm_small(x, a, self.norm1)
-            f = token_linear(F.relu(token_linear(x, self.linear1.weight, self.linear1.bias)), self.linear2.weight, self.linear2.bias)
-            return add_layer_norm_small(x, f, self.norm2)
+            return ffn_layer_norm(x, self.linear1, self.linear2, self.norm2)
         q, k, v = qkv.chunk(3, dim=-1)
         q, k, v = (t.reshape(S, B * h, d).transpose(0, 1).reshape(B, h, S, d) for t in (q, k, v))
         a = F.scaled_dot_product_attention(q, k, v)                    # [B, h, S, d]
@@ -338,6 +388,7 @@ class MAPPOAgent(nn.Module):
             if m.bias is not None:
                 m.bias.data.fill_(0.0)
 
+    fused_ffn = True        # use the fused feed-forward + LayerNorm kernels of the critic's encoder layers (bf16 on the GPU)
     fused_tower = True      # use the fused actor-tower kernels where they apply (bf16 on the GPU, supported board size)
     tower_pack = None       # packed tower parameters for inference, set by a caller that knows the weights are frozen
                             # (VecMAPPOTrainer.rollout); None = pack on every call
