@@ -159,6 +159,14 @@ int pmx_successor(pmx_env *env, int agent, const int8_t *actions_dev, int32_t *s
  * gymPacMan.py:195-229; GameState.getLegalActions, capture.py:101-105). */
 int pmx_observe(pmx_env *env, void *obs_dev, uint8_t *legal_dev, void *stream);
 
+/* What the MAPPO rollout does with every tick's observations (pacman_mappo_resnet.py:462-469), straight from the env: the two
+ * observations of one team -- agents (0, 2) when team_red, else (1, 3); agent i's planes from the state right after its own
+ * sub-step, exactly as pmx_step emits them -- written as team_obs_dev [n_envs][2][8][H][W] of the handle's obs_dtype and
+ * CANONICALISED for a red team (canonicalize_obs :215-229: x flipped, planes 2 <-> 3 and 6 <-> 7 swapped), plus, if merged_dev
+ * is not NULL, merge_obs_for_critic of the two (:267-274) as [n_envs][8][H][W].  Valid after pmx_step (tick observations) and
+ * after pmx_reset / pmx_set_state (all agents see the current state). */
+int pmx_emit_team_obs(pmx_env *env, int team_red, void *team_obs_dev, void *merged_dev, void *stream);
+
 /* Host copies of `count` games starting at `first`.  These two calls synchronise the stream. */
 int pmx_get_state(pmx_env *env, int32_t first, int32_t count, pmx_state *states, void *stream);
 int pmx_set_state(pmx_env *env, int32_t first, int32_t count, const pmx_state *states, void *stream);

@@ -61,6 +61,7 @@ PROTOTYPES = [
     ("pmx_step_agent", C.c_int, [_VP, C.c_int, _VP, C.POINTER(StepOut), _VP]),
     ("pmx_successor", C.c_int, [_VP, C.c_int, _VP, _VP, _VP]),
     ("pmx_observe", C.c_int, [_VP, _VP, _VP, _VP]),
+    ("pmx_emit_team_obs", C.c_int, [_VP, C.c_int, _VP, _VP, _VP]),
     ("pmx_get_state", C.c_int, [_VP, _I32, _I32, C.POINTER(State), _VP]),
     ("pmx_set_state", C.c_int, [_VP, _I32, _I32, C.POINTER(State), _VP]),
     ("pmx_maze_distances", C.c_int, [_VP, _VP, _VP, C.POINTER(_I32), _VP]),

@@ -13,6 +13,7 @@ extern "C" hipError_t pmx_launch_rule(const PmxTickParams *p, int H, hipStream_t
 extern "C" hipError_t pmx_launch_rule_agent(const PmxTickParams *p, int H, int agent, hipStream_t st);
 extern "C" hipError_t pmx_launch_reset(const PmxTickParams *p, int H, hipStream_t st);
 extern "C" hipError_t pmx_launch_successor(const PmxTickParams *p, int H, int agent, hipStream_t st);
+extern "C" hipError_t pmx_launch_emit_team(const PmxEmitParams *p, int dtype, hipStream_t st);
 extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, const PmxExpandTuning *tune, int dtype, hipStream_t st, hipEvent_t ev0,
                                          hipEvent_t ev1);
 extern "C" hipError_t pmx_launch_maze(const PmxLayoutDev *lay_dev, const int16_t *cell_index_dev, int n_cells,
@@ -44,6 +45,7 @@ struct pmx_env {
     bool profiling;
     uint64_t expand_launches = 0;   // parity selects the direction of the expansion sweep
     PmxExpandTuning tune;           // launch tuning, read from the environment once at pmx_create
+    bool snaps_valid = false;       // the three sub-step snapshots belong to the current state (set by pmx_step)
     std::vector<hipEvent_t> ev_rule, ev_expand;
     size_t ev_rule_used, ev_expand_used;
 };
@@ -371,6 +373,7 @@ int pmx_obs_shape(const pmx_env *env, int32_t *n_emit, int32_t *height, int32_t 
 int pmx_reset(pmx_env *env, const uint8_t *mask_dev, const pmx_step_out *out, void *stream)
 {
     if (!env) return fail(PMX_ERR_INVALID, "null env");
+    env->snaps_valid = false;      // the sub-step snapshots no longer describe the current state
     PmxTickParams p;
     fill_tick_params(env, p, nullptr, nullptr);
     p.reset_mask = mask_dev;
@@ -389,13 +392,34 @@ int pmx_step(pmx_env *env, const int8_t *actions_dev, const pmx_step_out *out, v
     fill_tick_params(env, p, actions_dev, out);
     hipEvent_t *ev = prof_pair(env, false);
     HIP_TRY(pmx_launch_rule(&p, env->lay.H, as_stream(stream), ev ? ev[0] : nullptr, ev ? ev[1] : nullptr));
+    env->snaps_valid = true;
     if (out && out->obs_dev) return launch_expand(env, out->obs_dev, true, -1, as_stream(stream));
+    return PMX_OK;
+}
+
+int pmx_emit_team_obs(pmx_env *env, int team_red, void *team_obs_dev, void *merged_dev, void *stream)
+{
+    if (!env || !team_obs_dev) return fail(PMX_ERR_INVALID, "pmx_emit_team_obs: null argument");
+    if (env->open_agent != 0) return fail(PMX_ERR_INVALID, "pmx_emit_team_obs: a tick opened with pmx_step_agent is unfinished");
+    PmxEmitParams x;
+    std::memset(&x, 0, sizeof(x));
+    const size_t snap_sz = (size_t)PMX_SNAP_WORDS(env->lay.H) * env->cfg.n_envs;
+    for (int a = 0; a < 4; ++a) x.snap[a] = (env->snaps_valid && a < 3) ? env->snap_dev + a * snap_sz : env->state_dev;
+    x.lay = env->lay_dev;
+    x.layout_idx = env->layout_idx_dev;
+    x.team_obs = team_obs_dev;
+    x.merged = merged_dev;
+    x.N = env->cfg.n_envs;
+    x.red = team_red ? 1 : 0;
+    x.lay_H = env->lay.H, x.lay_W = env->lay.W;
+    HIP_TRY(pmx_launch_emit_team(&x, env->cfg.obs_dtype, as_stream(stream)));
     return PMX_OK;
 }
 
 int pmx_step_agent(pmx_env *env, int agent, const int8_t *actions_dev, const pmx_step_out *out, void *stream)
 {
     if (!env || !actions_dev) return fail(PMX_ERR_INVALID, "pmx_step_agent: null argument");
+    env->snaps_valid = false;      // the sub-step snapshots no longer describe the current state
     if (agent != env->open_agent)
         return fail(PMX_ERR_INVALID, "pmx_step_agent: expected agent %d, got %d (sub-steps run 0,1,2,3)", env->open_agent, agent);
     PmxTickParams p;
@@ -409,6 +433,7 @@ int pmx_step_agent(pmx_env *env, int agent, const int8_t *actions_dev, const pmx
 int pmx_successor(pmx_env *env, int agent, const int8_t *actions_dev, int32_t *score_change_dev, void *stream)
 {
     if (!env || !actions_dev) return fail(PMX_ERR_INVALID, "pmx_successor: null argument");
+    env->snaps_valid = false;      // the sub-step snapshots no longer describe the current state
     if (agent < 0 || agent > 3) return fail(PMX_ERR_INVALID, "pmx_successor: agent %d out of range", agent);
     PmxTickParams p;
     fill_tick_params(env, p, actions_dev, nullptr);
@@ -528,6 +553,7 @@ int pmx_get_state(pmx_env *env, int32_t first, int32_t count, pmx_state *states,
 int pmx_set_state(pmx_env *env, int32_t first, int32_t count, const pmx_state *states, void *stream)
 {
     if (!env || !states) return fail(PMX_ERR_INVALID, "pmx_set_state: null argument");
+    env->snaps_valid = false;      // the sub-step snapshots no longer describe the current state
     const int N = env->cfg.n_envs, H = env->lay.H, W = env->lay.W;
     if (first < 0 || count < 0 || first + count > N) return fail(PMX_ERR_INVALID, "pmx_set_state: range outside [0,%d)", N);
     if (count == 0) return PMX_OK;

@@ -85,6 +85,17 @@ struct PmxExpandParams {
     int32_t reverse;             // 1: walk the blocks from the highest address down (alternate ticks, see pmx_launch_expand)
 };
 
+// pmx_emit_team_obs: the two observations of one team, canonicalised for a red team, + the merged critic input
+struct PmxEmitParams {
+    const uint32_t *snap[4];     // per agent: the snapshot its planes are encoded from (as in PmxExpandParams)
+    const PmxLayoutDev *lay;
+    const int32_t *layout_idx;
+    void *team_obs;              // [N][2][8][H][W]
+    void *merged;                // [N][8][H][W] or NULL
+    int32_t N, red;              // red: agents (0, 2), x-flipped with planes 2<->3 and 6<->7 swapped; else agents (1, 3) as they are
+    int32_t lay_H, lay_W;
+};
+
 // Host-side launch tuning of the expansion kernel: -1 = the built-in choice.  Filled once per handle at pmx_create (from the
 // PMX_EXPAND_* environment variables, for experiments) and changed through pmx_set_tuning; never read at launch time.
 struct PmxExpandTuning {

@@ -844,6 +844,145 @@ __global__ __launch_bounds__(PMX_BLOCK) void pmx_expand_kernel(PmxExpandParams p
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Training-side emission: what the MAPPO rollout does with every tick's observations (pacman_mappo_resnet.py:462-469),
+// straight from the snapshots: the two learners' planes -- canonicalised for a red team (canonicalize_obs :215-229: x
+// flipped, capsule planes 2 <-> 3 and food planes 6 <-> 7 swapped) -- and merge_obs_for_critic (:267-274: the first
+// learner's planes with plane 4 cleared and plane 1 = max of both learners' self planes).  One wavefront per (env, slot),
+// slots 0, 1 = the learners, slot 2 = the merged input; same packed-bit-stream construction and look-up-table expansion
+// as pmx_expand_kernel, with the flip applied while the stream is built (rows bit-reversed, x -> W-1-x).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t flip_row(uint32_t v, int W, bool flip) { return flip ? (__builtin_bitreverse32(v) >> (32 - W)) : v; }
+
+template <int DT>
+__global__ __launch_bounds__(PMX_BLOCK) void pmx_emit_team_kernel(PmxEmitParams p)
+{
+    constexpr int VEC = ObsVec<DT>::VEC;
+    __shared__ uint32_t tab[4][8 * 32 * 32 / 32 + 8];
+    __shared__ __align__(16) uint32_t lut[DT == 0 ? 16 * 4 : (DT == 1 ? 256 * 4 : 256 * 2)];
+    {
+        const uint32_t i = threadIdx.x;
+        if (DT == 0) {
+            if (i < 16) *reinterpret_cast<uint4 *>(&lut[4 * i]) = pack_obs<0>(i);
+        } else if (DT == 1) {
+            *reinterpret_cast<uint4 *>(&lut[4 * i]) = pack_obs<1>(i);
+        } else {
+            lut[2 * i] = ((i & 15u) * 0x00204081u) & 0x01010101u;
+            lut[2 * i + 1] = ((i >> 4) * 0x00204081u) & 0x01010101u;
+        }
+        __syncthreads();
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int W = p.lay_W, H = p.lay_H, HW = H * W;
+    const int n_slots = p.merged ? 3 : 2;
+    const long q = (long)blockIdx.x * 4 + wave;
+    if (q >= (long)p.N * n_slots) return;
+    const long env = q / n_slots;
+    const int slot = (int)(q - env * n_slots);
+    const bool flip = p.red != 0, merged = slot == 2;
+    const int first = p.red ? 0 : 1, second = first + 2;
+    const int agent = slot == 1 ? second : first;             // the merged input is built on the first learner's planes
+    const size_t N = (size_t)p.N;
+    const uint32_t *S = p.snap[agent] + env;
+    uint32_t *T = tab[wave];
+    const PmxLayoutDev *L = p.lay + (p.layout_idx ? p.layout_idx[env] : 0);
+
+    const uint32_t food = lane < H ? S[(size_t)lane * N] : 0u;
+    uint32_t pt = 0;
+    if (lane < 4) pt = S[(size_t)PMX_W_AGENT_A(H, lane) * N];
+    else if (lane < 8) pt = S[(size_t)PMX_W_CAPS(H, (lane - 4) >> 1) * N];
+    const uint32_t a_self = S[(size_t)PMX_W_AGENT_A(H, agent) * N];
+    const uint32_t b_self = S[(size_t)PMX_W_AGENT_B(H, agent) * N];
+    uint32_t a_mate = 0, b_mate = 0;                          // the second learner after ITS sub-step (merged slot only)
+    if (merged) {
+        const uint32_t *S2 = p.snap[second] + env;
+        a_mate = S2[(size_t)PMX_W_AGENT_A(H, second) * N];
+        b_mate = S2[(size_t)PMX_W_AGENT_B(H, second) * N];
+    }
+    const int n_words = (8 * HW + 31) >> 5;
+    const int wall_words = (HW + 31) >> 5;
+    for (int k = lane; k < n_words + 1; k += 64) T[k] = (!flip && k < wall_words) ? L->wall_stream[k] : 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < H) {
+        if (flip) stream_or_row(T, (uint32_t)(lane * W), flip_row(L->walls[lane], W, true), W);
+        const uint32_t blue = flip_row(food & L->hi_mask, W, flip), red = flip_row(food & L->lo_mask, W, flip);
+        stream_or_row(T, (uint32_t)(((flip ? 7 : 6) * H + lane) * W), blue, W);     // plane 6: food with x >= int(W/2); swapped by the flip
+        stream_or_row(T, (uint32_t)(((flip ? 6 : 7) * H + lane) * W), red, W);
+    }
+    if (lane < 4) {
+        const int x0 = pt & 0xFF, y = (pt >> 8) & 0xFF, x = flip ? W - 1 - x0 : x0;
+        const int plane = lane == agent ? 1 : (((lane ^ agent) == 2) ? 4 : 5);
+        if (!(merged && plane == 4)) {                                               // merge_obs_for_critic clears plane 4
+            const uint32_t off = (uint32_t)((plane * H + y) * W + x);
+            atomicOr(&T[off >> 5], 1u << (off & 31));
+        }
+    } else if (lane < 8) {
+        const uint32_t cxy = (pt >> (16 * ((lane - 4) & 1))) & 0xFFFFu;
+        if (cxy != 0xFFFFu) {
+            const int x0 = cxy & 0xFF, y = cxy >> 8, x = flip ? W - 1 - x0 : x0;
+            const int plane0 = (2 * x0 > W) ? 2 : 3;
+            const int plane = flip ? 5 - plane0 : plane0;
+            const uint32_t off = (uint32_t)((plane * H + y) * W + x);
+            atomicOr(&T[off >> 5], 1u << (off & 31));
+        }
+    }
+    uint32_t carry = (b_self >> 8) & 0xFFF;
+    const int sx = (int)(a_self & 0xFF);
+    const int fself = (H + (int)((a_self >> 8) & 0xFF)) * W + (flip ? W - 1 - sx : sx);
+    int fmate = -1;
+    uint32_t carry_mate = 0;
+    if (merged) {
+        const int mx = (int)(a_mate & 0xFF);
+        fmate = (H + (int)((a_mate >> 8) & 0xFF)) * W + (flip ? W - 1 - mx : mx);
+        carry_mate = (b_mate >> 8) & 0xFFF;
+        if (fmate == fself) {                                  // both learners on one cell: max(1 + carry, 1 + carry')
+            carry = carry > carry_mate ? carry : carry_mate;
+            fmate = -1;
+        } else if (lane == 0) {
+            atomicOr(&T[(uint32_t)fmate >> 5], 1u << ((uint32_t)fmate & 31));
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const int n_vec = 8 * HW / VEC;
+    uint4 *out = merged ? reinterpret_cast<uint4 *>(p.merged) + (size_t)env * n_vec
+                        : reinterpret_cast<uint4 *>(p.team_obs) + ((size_t)env * 2 + slot) * n_vec;
+    for (int k = lane; k < n_vec; k += 64) {
+        const uint32_t e0 = (uint32_t)k * VEC;
+        const uint32_t bits = T[e0 >> 5] >> (e0 & 31);
+        uint4 v;
+        if (DT == 0) v = *reinterpret_cast<const uint4 *>(&lut[(bits & 15u) * 4]);
+        else if (DT == 1) v = *reinterpret_cast<const uint4 *>(&lut[(bits & 255u) * 4]);
+        else {
+            const uint2 lo = *reinterpret_cast<const uint2 *>(&lut[(bits & 255u) * 2]);
+            const uint2 hi = *reinterpret_cast<const uint2 *>(&lut[((bits >> 8) & 255u) * 2]);
+            v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+        const uint32_t d = (uint32_t)(fself - (int)e0);
+        if (d < (uint32_t)VEC) patch_self<DT>(v, (int)d, carry);
+        if (fmate >= 0) {
+            const uint32_t d2 = (uint32_t)(fmate - (int)e0);
+            if (d2 < (uint32_t)VEC) patch_self<DT>(v, (int)d2, carry_mate);
+        }
+        out[k] = v;
+    }
+}
+
+extern "C" hipError_t pmx_launch_emit_team(const PmxEmitParams *p, int dtype, hipStream_t st)
+{
+    const long waves = (long)p->N * (p->merged ? 3 : 2);
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    switch (dtype) {
+    case 0: hipLaunchKernelGGL(pmx_emit_team_kernel<0>, dim3(blocks), dim3(PMX_BLOCK), 0, st, *p); break;
+    case 1: hipLaunchKernelGGL(pmx_emit_team_kernel<1>, dim3(blocks), dim3(PMX_BLOCK), 0, st, *p); break;
+    default: hipLaunchKernelGGL(pmx_emit_team_kernel<2>, dim3(blocks), dim3(PMX_BLOCK), 0, st, *p); break;
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host-side launchers (called by the C ABI in pmx_api.hip)
 // ---------------------------------------------------------------------------------------------------------------
 // ev0/ev1 (both or neither): events that receive the START and STOP timestamps of this very dispatch (hipExtLaunchKernelGGL),

@@ -124,7 +124,8 @@ class VecMAPPOTrainer:
         starts = self.env.layout.starts.astype(np.int64)
         self.start_words = torch.tensor([int(starts[i, 0]) | (int(starts[i, 1]) << 8) for i in range(4)],
                                         dtype=torch.int32, device=dev)
-        self.cur_obs, _ = self.env.reset()
+        self.env.reset()
+        self._acts = None                                          # persistent per-rollout tensors, allocated on first use
         self.prev_agent = self.start_words[None].expand(N, 4).clone()
         self.update_idx = 0
         self.stats = {}
@@ -186,6 +187,10 @@ class VecMAPPOTrainer:
         return mode, play_as_red
 
     def rollout(self):
+        """T ticks.  Per tick (pacman_mappo_resnet.py:461-546, N envs at once): the env itself writes the learners' (canonicalised)
+        observations into obs_buf[t] and the merged critic input into merged_buf[t] (pmx_emit_team_obs -- no select / flip /
+        copy / merge passes over the planes, and the four-agent observation tensor of pmx_step is not produced at all), the
+        policy samples both learners' actions and one value, the env steps with the actions taken from a persistent tensor."""
         env, N, T = self.env, self.N, self.T
         mode, red = self._pick_opponent()
         self._freeze_tower_packs(True)
@@ -195,34 +200,34 @@ class VecMAPPOTrainer:
         ep_ret = torch.zeros((), dtype=torch.float64, device=self.device)
         n_done = torch.zeros((), dtype=torch.int64, device=self.device)
         n_win = torch.zeros((), dtype=torch.int64, device=self.device)
+        if self._acts is None:
+            dt = self.obs_buf.dtype
+            self._acts = torch.empty((N, 4), dtype=torch.int8, device=self.device)
+            self._opp_obs = torch.empty((N, 2) + self.obs_shape, dtype=dt, device=self.device)
+            self._boot_obs = torch.empty((N, 2) + self.obs_shape, dtype=dt, device=self.device)
+            self._boot_merged = torch.empty((N,) + self.obs_shape, dtype=dt, device=self.device)
+        acts = self._acts
+        acts.fill_(_lib.ACTION_RANDOM_LEGAL)
+        if mode == "baseline":                                       # createTeam: first index offensive, second defensive
+            acts[:, opp_ids[0]] = _lib.ACTION_BASELINE_OFFENSE
+            acts[:, opp_ids[1]] = _lib.ACTION_BASELINE_DEFENSE
+        mappo_alg = self.algorithm == "mappo"
         for t in range(T):
-            raw = self.cur_obs                                       # [N,4,8,H,W], the env's own output buffer
-            lo = raw[:, learner_ids]
-            if red:
-                lo = canonicalize_obs(lo)
-            self.obs_buf[t].copy_(lo)
-            merged = merge_obs(self.obs_buf[t, :, 0], self.obs_buf[t, :, 1])
-            self.merged_buf[t].copy_(merged)
-            if self.algorithm == "mappo":
-                a, lp, v = self._forward_policy(self.model, self.obs_buf[t], merged, True)
+            env.emit_team_obs(red, self.obs_buf[t], self.merged_buf[t] if mappo_alg else None)
+            if mappo_alg:
+                a, lp, v = self._forward_policy(self.model, self.obs_buf[t], self.merged_buf[t], True)
                 self.val_buf[t].copy_(v[:, None].expand(N, 2))
             else:
                 a, lp, v = self._forward_policy(self.model, self.obs_buf[t], self.obs_buf[t].view((-1,) + self.obs_shape), True)
                 self.val_buf[t].copy_(v.view(N, 2))
             self.act_buf[t].copy_(a)
             self.logp_buf[t].copy_(lp)
-            acts = torch.full((N, 4), _lib.ACTION_RANDOM_LEGAL, dtype=torch.int8, device=self.device)
-            if mode == "baseline":                                   # createTeam: first index offensive, second defensive
-                acts[:, opp_ids[0]] = _lib.ACTION_BASELINE_OFFENSE
-                acts[:, opp_ids[1]] = _lib.ACTION_BASELINE_DEFENSE
             acts[:, learner_ids] = mappo.canonicalize_action(a, red).to(torch.int8)
             if mode in ("self", "pool"):
-                oo = raw[:, opp_ids]
-                if not red:
-                    oo = canonicalize_obs(oo)                        # the opponent is red when the learner is blue
-                oa, _, _ = self._forward_policy(self.opponent_model, oo, None, False)
+                env.emit_team_obs(not red, self._opp_obs, None)      # the opponent is red when the learner is blue
+                oa, _, _ = self._forward_policy(self.opponent_model, self._opp_obs, None, False)
                 acts[:, opp_ids] = mappo.canonicalize_action(oa, not red).to(torch.int8)
-            obs, rew, done, info = env.step(acts)
+            _, rew, done, info = env.step(acts, want_obs=False)
             cur_agent = info["agent"]
             shp = shaping_from_agent_words(self.prev_agent[:, learner_ids], cur_agent[:, learner_ids])   # [N,2] f64
             team_reward = rew[:, team] + rew[:, team]                # sum over the two learners' (identical) rewards
@@ -234,18 +239,14 @@ class VecMAPPOTrainer:
             n_done += d.sum()
             sc = info["score"]
             n_win += (d & ((sc > 0) if red else (sc < 0))).sum()
-            self.cur_obs = obs
         # bootstrap value of the state after the last tick (:541-546)
-        lo = self.cur_obs[:, learner_ids]
-        if red:
-            lo = canonicalize_obs(lo)
+        env.emit_team_obs(red, self._boot_obs, self._boot_merged if mappo_alg else None)
         ctx = torch.autocast(device_type=self.device.type, dtype=self.autocast_dtype) if self.autocast_dtype else _NullCtx()
         with torch.no_grad(), ctx:
-            if self.algorithm == "mappo":
-                last_merged = merge_obs(lo[:, 0].contiguous(), lo[:, 1].contiguous())
-                self.last_value = self.model.value(self._net_in(last_merged)).float()[:, None].expand(N, 2).contiguous()
+            if mappo_alg:
+                self.last_value = self.model.value(self._net_in(self._boot_merged)).float()[:, None].expand(N, 2).contiguous()
             else:
-                self.last_value = self.model.value(self._net_in(lo.reshape((-1,) + self.obs_shape))).float().view(N, 2)
+                self.last_value = self.model.value(self._net_in(self._boot_obs.view((-1,) + self.obs_shape))).float().view(N, 2)
         self._freeze_tower_packs(False)
         self.stats.update(opponent=mode, play_as_red=red, rollout_reward=ep_ret, episodes=n_done, wins=n_win)
 

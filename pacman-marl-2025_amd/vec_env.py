@@ -174,6 +174,18 @@ class PmxVecEnv:
                                             self.legal.data_ptr() if want_legal else None, self._stream()), "pmx_observe")
         return self.obs, self.legal
 
+    def emit_team_obs(self, team_red, team_obs, merged=None):
+        """The two observations of one team for the CURRENT tick (canonicalised for red) into team_obs [N,2,8,H,W] and, if
+        given, the merged critic input into merged [N,8,H,W] (pmx_emit_team_obs; pacman_mappo_resnet.py:215-229, :267-274)."""
+        N = self.n_envs
+        assert team_obs.shape == (N, 2) + self.obs_shape and team_obs.dtype == self.obs_torch_dtype and team_obs.is_contiguous()
+        if merged is not None:
+            assert merged.shape == (N,) + self.obs_shape and merged.dtype == self.obs_torch_dtype and merged.is_contiguous()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.pmx_emit_team_obs(self.handle, int(bool(team_red)), team_obs.data_ptr(),
+                                                  merged.data_ptr() if merged is not None else None, self._stream()), "pmx_emit_team_obs")
+        return team_obs, merged
+
     # -- measurement ---------------------------------------------------------------------------------------------
     def profile_begin(self, max_launches):
         _lib.check(self.lib.pmx_profile_begin(self.handle, int(max_launches)), "pmx_profile_begin")

@@ -545,3 +545,51 @@ def test_soak_four_episodes_mixed_controllers_vs_oracle(layname):
     assert n_done >= 4 * N                              # at least the four time-outs; the bots also end games early by winning
     assert deaths > 0                                   # carriers did lose their food (kills with dumps happened)
     env.close()
+
+
+@pytest.mark.parametrize("layout", ["smallCapture", "tinyCapture", "bloxCapture"])
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16", "uint8"])
+def test_emit_team_obs_equals_canonicalize_and_merge_of_the_tick_observations(layout, dtype):
+    """pmx_emit_team_obs against the step's own four observations pushed through canonicalize_obs / merge_obs_for_critic (the
+    torch forms are pinned by fixture G8 in tests/test_gpu_trainer.py): both colours, every tick of 70 with random play and
+    auto-reset (staggered snapshots, carried food, resets), right after a reset, and with both learners on ONE cell carrying
+    different amounts (plane 1 of the merged input is a max)."""
+    import pmx
+    from pmx import trainer
+    N = 192
+    env = pmx.PmxVecEnv(layout, N, length=25, auto_reset=True, obs_dtype=dtype, seed=9)
+    H, W = env.layout.height, env.layout.width
+    team = torch.empty((N, 2, 8, H, W), dtype=env.obs_torch_dtype, device="cuda")
+    merged = torch.empty((N, 8, H, W), dtype=env.obs_torch_dtype, device="cuda")
+
+    def check(raw, tag):
+        for red in (False, True):
+            ids = [0, 2] if red else [1, 3]
+            want = raw[:, ids].float()
+            if red:
+                want = trainer.canonicalize_obs(want)
+            want_m = trainer.merge_obs(want[:, 0].contiguous(), want[:, 1].contiguous())
+            env.emit_team_obs(red, team, merged)
+            assert torch.equal(team.float(), want), (tag, red)
+            assert torch.equal(merged.float(), want_m), (tag, red)
+            team.fill_(7); env.emit_team_obs(red, team, None)
+            assert torch.equal(team.float(), want), (tag, red, "no merged")
+
+    obs, _ = env.reset()
+    check(obs.clone(), "reset")
+    g = torch.Generator(device="cuda").manual_seed(4)
+    for t in range(70):
+        # mostly legal-ish random play with a bias to the east/west so that agents cross the border and carry food
+        a = torch.randint(0, 5, (N, 4), generator=g, device="cuda", dtype=torch.int8)
+        obs, _, _, _ = env.step(a)
+        check(obs.clone(), t)
+    # both blue learners (and both red ones) on one cell with different loads
+    st = env.get_state(0, N)
+    for k in range(N):
+        for i, j in ((1, 3), (0, 2)):
+            st[k].pos[j][0], st[k].pos[j][1] = st[k].pos[i][0], st[k].pos[i][1]
+            st[k].carry[i], st[k].carry[j] = 1 + (k % 5), 3
+    env.set_state(st)
+    obs, _ = env.observe()
+    check(obs.clone(), "same cell")
+    env.close()
