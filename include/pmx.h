@@ -80,12 +80,18 @@ typedef struct {
     int32_t device;              /* HIP device ordinal */
     uint32_t seed;               /* key of the PMX_ACTION_RANDOM_LEGAL generator */
     int32_t n_layouts;           /* 0 or 1: every env plays the one layout above.  L > 1: wall_rows / food_rows / cap_rows
-                                    hold [L][height] rows and starts [L][4][2]; all layouts share width x height
-                                    (gymPacMan's random_layout=True draws a new maze per reset, gymPacMan.py:98-100; here
-                                    each env keeps the maze it is given) */
+                                    hold [L][height] rows and starts [L][4][2]; all layouts share width x height; an env
+                                    keeps the layout it is given unless redraw_layouts is set (below) */
     const int32_t *layout_index; /* [n_envs] host array: layout of each env (required when n_layouts > 1) */
     int32_t enable_bots;         /* 1: keep every layout's maze-distance matrix on the device and use the tick kernel variant
                                     that understands PMX_ACTION_BASELINE_* (it is a few microseconds per tick slower) */
+    int32_t redraw_layouts;      /* 1 (needs n_layouts > 1): random_layout=True of the reference (gymPacMan.py:98-100 draws a new
+                                    maze at every reset()): whenever an env is reset -- by pmx_reset or by the auto-reset inside
+                                    pmx_step -- it moves to layout floor(u * n_layouts) of the pool, u from the counter-based
+                                    generator keyed by (seed, env index, the env's tick counter); the layouts are the pool the
+                                    host generated (maze_generator.py), layout_index gives the initial assignment.  The draw is
+                                    distribution-equivalent to the reference's (which reseeds Python's global generator per maze)
+                                    and is reproduced exactly by the test oracle. */
 } pmx_config;
 
 /* Outputs of one tick = what gymPacMan.step returns (gymPacMan.py:191-193), batched.  Any pointer may be
@@ -166,6 +172,9 @@ int pmx_observe(pmx_env *env, void *obs_dev, uint8_t *legal_dev, void *stream);
  * is not NULL, merge_obs_for_critic of the two (:267-274) as [n_envs][8][H][W].  Valid after pmx_step (tick observations) and
  * after pmx_reset / pmx_set_state (all agents see the current state). */
 int pmx_emit_team_obs(pmx_env *env, int team_red, void *team_obs_dev, void *merged_dev, void *stream);
+
+/* The layout each env is currently on (host output [n_envs]; all zeros for a single-layout handle).  Synchronises the stream. */
+int pmx_get_layout_index(pmx_env *env, int32_t *index_out, void *stream);
 
 /* Host copies of `count` games starting at `first`.  These two calls synchronise the stream. */
 int pmx_get_state(pmx_env *env, int32_t first, int32_t count, pmx_state *states, void *stream);

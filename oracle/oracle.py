@@ -196,8 +196,10 @@ class BatchEnv:
 class MultiBatchEnv:
     """N oracle envs, each with its own (equally sized) layout."""
 
-    def __init__(self, rows_list, layout_index, length=299, legal_reward=True, defence_reward=True, auto_reset=True, seed=0):
+    def __init__(self, rows_list, layout_index, length=299, legal_reward=True, defence_reward=True, auto_reset=True, seed=0,
+                 redraw=False):
         self.lib = lib()
+        self.redraw = bool(redraw)      # move an env to a freshly drawn layout of the pool at every reset (gymPacMan.py:98-100)
         self.Ls = [Layout(r) for r in rows_list]
         lsz = self.lib.orc_sizeof_layout()
         self.lbuf = C.create_string_buffer(lsz * len(self.Ls))
@@ -224,7 +226,7 @@ class MultiBatchEnv:
         self.lib.orc_tick_batch_multi(self.lbuf, self.index.ctypes, C.byref(self.cfg), self.S, self.n, a.ctypes,
                                       obs.ctypes if obs is not None else None, self.reward.ctypes, self.done.ctypes,
                                       self.legal.ctypes, self.score_change.ctypes, self.auto_reset, self.score.ctypes,
-                                      self.agent.ctypes)
+                                      self.agent.ctypes, len(self.Ls) if self.redraw else 0)
 
 
 def bot_tables(rows):

@@ -29,7 +29,7 @@ class Config(C.Structure):
                 ("n_envs", C.c_int32), ("length", C.c_int32), ("legal_reward", C.c_int32),
                 ("defence_reward", C.c_int32), ("auto_reset", C.c_int32), ("obs_dtype", C.c_int32),
                 ("obs_agents", C.c_int32), ("device", C.c_int32), ("seed", C.c_uint32), ("n_layouts", C.c_int32),
-                ("layout_index", C.POINTER(C.c_int32)), ("enable_bots", C.c_int32)]
+                ("layout_index", C.POINTER(C.c_int32)), ("enable_bots", C.c_int32), ("redraw_layouts", C.c_int32)]
 
 
 class StepOut(C.Structure):
@@ -62,6 +62,7 @@ PROTOTYPES = [
     ("pmx_successor", C.c_int, [_VP, C.c_int, _VP, _VP, _VP]),
     ("pmx_observe", C.c_int, [_VP, _VP, _VP, _VP]),
     ("pmx_emit_team_obs", C.c_int, [_VP, C.c_int, _VP, _VP, _VP]),
+    ("pmx_get_layout_index", C.c_int, [_VP, C.POINTER(_I32), _VP]),
     ("pmx_get_state", C.c_int, [_VP, _I32, _I32, C.POINTER(State), _VP]),
     ("pmx_set_state", C.c_int, [_VP, _I32, _I32, C.POINTER(State), _VP]),
     ("pmx_maze_distances", C.c_int, [_VP, _VP, _VP, C.POINTER(_I32), _VP]),

@@ -105,6 +105,8 @@ void fill_tick_params(pmx_env *env, PmxTickParams &p, const int8_t *actions, con
     p.snap = env->snap_dev;
     p.lay = env->lay_dev;
     p.layout_idx = env->layout_idx_dev;
+    p.layout_idx_rw = env->cfg.redraw_layouts ? env->layout_idx_dev : nullptr;
+    p.n_layouts = (int32_t)env->layouts.size();
     p.dist = env->dist_dev;
     p.cell_index = env->cell_index_dev;
     p.dump = env->dump_dev;
@@ -249,6 +251,7 @@ int pmx_create(const pmx_config *cfg, pmx_env **out)
         return fail(PMX_ERR_UNSUPPORTED, "uint8 observations need an even number of cells (16-byte rows of the stream)");
     const int n_layouts = cfg->n_layouts > 1 ? cfg->n_layouts : 1;
     if (n_layouts > 1 && !cfg->layout_index) return fail(PMX_ERR_INVALID, "n_layouts > 1 needs layout_index");
+    if (cfg->redraw_layouts && n_layouts < 2) return fail(PMX_ERR_INVALID, "redraw_layouts needs a pool of n_layouts > 1");
 
     pmx_env *env = new (std::nothrow) pmx_env();
     if (!env) return fail(PMX_ERR_NOMEM, "host allocation failed");
@@ -550,6 +553,27 @@ int pmx_get_state(pmx_env *env, int32_t first, int32_t count, pmx_state *states,
     return PMX_OK;
 }
 
+// with redraw_layouts the device owns the env -> layout map: refresh the host copy before it is used
+static int refresh_layout_index(pmx_env *env, hipStream_t st)
+{
+    if (!env->cfg.redraw_layouts || !env->layout_idx_dev) return PMX_OK;
+    HIP_TRY(hipMemcpyAsync(env->layout_index.data(), env->layout_idx_dev, env->layout_index.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PMX_OK;
+}
+
+int pmx_get_layout_index(pmx_env *env, int32_t *index_out, void *stream)
+{
+    if (!env || !index_out) return fail(PMX_ERR_INVALID, "pmx_get_layout_index: null argument");
+    if (env->layout_index.empty()) {
+        std::fill(index_out, index_out + env->cfg.n_envs, 0);
+        return PMX_OK;
+    }
+    if (int rc = refresh_layout_index(env, as_stream(stream))) return rc;
+    std::copy(env->layout_index.begin(), env->layout_index.end(), index_out);
+    return PMX_OK;
+}
+
 int pmx_set_state(pmx_env *env, int32_t first, int32_t count, const pmx_state *states, void *stream)
 {
     if (!env || !states) return fail(PMX_ERR_INVALID, "pmx_set_state: null argument");
@@ -557,6 +581,7 @@ int pmx_set_state(pmx_env *env, int32_t first, int32_t count, const pmx_state *s
     const int N = env->cfg.n_envs, H = env->lay.H, W = env->lay.W;
     if (first < 0 || count < 0 || first + count > N) return fail(PMX_ERR_INVALID, "pmx_set_state: range outside [0,%d)", N);
     if (count == 0) return PMX_OK;
+    if (int rc = refresh_layout_index(env, as_stream(stream))) return rc;
     const int words = PMX_STATE_WORDS(H);
     std::vector<uint32_t> buf((size_t)words * count, 0);
     for (int k = 0; k < count; ++k) {

@@ -71,6 +71,8 @@ struct PmxTickParams {
     // of behind a dependent load from the layout record
     int32_t lay_W, lay_H, lay_half, lay_n_dump;
     uint32_t lo_mask, hi_mask;
+    int32_t *layout_idx_rw;      // the same array as layout_idx when envs move to a new layout at every reset (redraw), else NULL
+    int32_t n_layouts;
 };
 
 struct PmxExpandParams {

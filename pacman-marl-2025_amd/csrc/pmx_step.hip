@@ -442,6 +442,26 @@ __device__ __forceinline__ void store_env(const Env &e, const Ctx &c, uint32_t *
     st[(size_t)PMX_W_STEPS(c.H) * N + env] = (uint32_t)e.steps;
     st[(size_t)PMX_W_TICKS(c.H) * N + env] = e.ticks;
 }
+// random_layout=True (gymPacMan.py:98-100): the layout an env moves to when it is reset; counter-based draw keyed by
+// (seed, env, the env's tick counter), reproduced by the oracle (orc_redraw_layout)
+__device__ __forceinline__ int redraw_layout(uint32_t key, uint32_t ticks, int n_layouts)
+{
+    uint32_t x = key ^ (ticks * 0x85EBCA77u) ^ 0x4C41594Fu;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return (int)(((uint64_t)x * (uint32_t)n_layouts) >> 32);
+}
+
+// point the lane's context at another layout of the pool: layout record, start cells, and the lane's wall column in LDS
+__device__ __forceinline__ void switch_layout(Ctx &c, const PmxTickParams &p, int env, int li)
+{
+    p.layout_idx_rw[env] = li;
+    c.L = p.lay + li;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c.start_xy[i] = (uint32_t)c.L->startx[i] | ((uint32_t)c.L->starty[i] << 8);
+    uint32_t *w = const_cast<uint32_t *>(c.wl);
+    for (int y = 0; y < 32; ++y) w[y * c.wls] = y < c.H ? c.L->walls[y] : 0xFFFFFFFFu;
+}
+
 __device__ __forceinline__ void init_env(Env &e, const Ctx &c)
 {
     for (int y = 0; y < c.H; ++y) c.fd[y * PMX_RULE_BLOCK] = c.L->food0[y];
@@ -456,8 +476,9 @@ __device__ __forceinline__ void init_env(Env &e, const Ctx &c)
 
 // gymPacMan.py:171-193: everything after the four sub-steps.
 template <int HB = 0>
-__device__ __forceinline__ void tick_finish(Env &e, Acc &a, const Ctx &c, const PmxTickParams &p, int env, bool fused)
+__device__ __forceinline__ void tick_finish(Env &e, Acc &a, const Ctx &c_in, const PmxTickParams &p, int env, bool fused)
 {
+    Ctx c = c_in;             // a reset may move the env to another layout of the pool (redraw_layouts)
     double blue_r = a.blue_r + (double)(a.blue_sc > 0 ? a.blue_sc : 0);   // :171-172
     double red_r = a.red_r + (double)(a.red_sc > 0 ? a.red_sc : 0);
     int n_red = 0, n_blue = 0;                                            // capture.py:332-342 halfGrid sums
@@ -493,6 +514,7 @@ __device__ __forceinline__ void tick_finish(Env &e, Acc &a, const Ctx &c, const 
     if (p.score_change) p.score_change[env] = a.sc_total;
     if (p.score) p.score[env] = e.score;
     if (done && p.auto_reset) {
+        if (p.layout_idx_rw) switch_layout(c, p, env, redraw_layout(c.rng_key, e.ticks, p.n_layouts));
         init_env(e, c);
         // the observations of a finished env are those of the fresh game for all four agents (gymPacMan.py:135-137)
         const size_t snap_sz = (size_t)PMX_SNAP_WORDS(c.H) * p.N;
@@ -652,8 +674,9 @@ extern "C" __global__ __launch_bounds__(PMX_RULE_BLOCK) void pmx_reset_kernel(Pm
     if (env >= p.N) return;
     Env e;
     if (!p.no_reset && (!p.reset_mask || p.reset_mask[env])) {
-        init_env(e, c);
         e.ticks = p.state[(size_t)PMX_W_TICKS(c.H) * p.N + env];
+        if (p.layout_idx_rw) switch_layout(c, p, env, redraw_layout(c.rng_key, e.ticks, p.n_layouts));
+        init_env(e, c);
         store_env(e, c, p.state, p.N, env);
         for (int k = 0; k < 7; ++k) p.state[(size_t)(PMX_W_ACC(c.H) + k) * p.N + env] = 0;
     } else if (p.legal) {

@@ -56,7 +56,7 @@ class VecMAPPOTrainer:
     def __init__(self, layout, n_envs, horizon=32, minibatch=512, epochs=UPDATE_EPOCHS, obs_dtype=None,
                  device="cuda:0", seed=0, rank=0, world_size=1, process_group=None, total_updates=2000, length=300,
                  use_autocast=True, opponent="random", use_graph=False, algorithm="mappo", paired_minibatches=True, flat_bf16=False, curriculum_scale=1.0,
-                 env=None):
+                 env=None, redraw_layouts=False):
         self.device = torch.device(device)
         self.rank, self.world_size = rank, world_size
         if obs_dtype is None:
@@ -68,7 +68,7 @@ class VecMAPPOTrainer:
         # without a GPU
         self.env = env if env is not None else PmxVecEnv(
             layout, n_envs, length=length, reward_forLegalAction=True, defenceReward=True, auto_reset=True, obs_dtype=obs_dtype,
-            device=self.device, seed=seed * 1000003 + rank, bots=opponent in ("baseline", "curriculum"))
+            device=self.device, seed=seed * 1000003 + rank, bots=opponent in ("baseline", "curriculum"), redraw_layouts=redraw_layouts)
         self.N, self.T = n_envs, horizon
         self.minibatch, self.epochs = minibatch, epochs
         # "mappo": centralised critic on merge_obs_for_critic of the two learners (the reference).  "ippo": the same network

@@ -24,7 +24,8 @@ def legal_list(mask):
 
 class PmxVecEnv:
     def __init__(self, layout, n_envs, length=299, reward_forLegalAction=True, defenceReward=True, auto_reset=True,
-                 obs_dtype="float32", obs_agents=(0, 1, 2, 3), device="cuda:0", seed=0, layout_index=None, bots=False):
+                 obs_dtype="float32", obs_agents=(0, 1, 2, 3), device="cuda:0", seed=0, layout_index=None, bots=False,
+                 redraw_layouts=False):
         if not torch.cuda.is_available():
             raise _lib.PmxError("PmxVecEnv needs a GPU: the product has no CPU path")
         self.lib = _lib.load()
@@ -73,6 +74,11 @@ class PmxVecEnv:
         cfg.obs_agents = sum(1 << a for a in self.obs_agents)
         cfg.device = self.device.index or 0
         cfg.seed = int(seed) & 0xFFFFFFFF
+        # random_layout=True of the reference (gymPacMan.py:98-100): an env moves to a freshly drawn layout of the pool at every
+        # reset; `layout` is then the pool of generated mazes
+        cfg.redraw_layouts = int(bool(redraw_layouts))
+        if redraw_layouts and len(L) < 2:
+            raise ValueError("redraw_layouts needs a pool of at least two layouts")
         cfg.enable_bots = int(bool(bots))          # understand ACTION_BASELINE_OFFENSE / _DEFENSE (in-kernel baselineTeam)
         self.handle = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -213,6 +219,14 @@ class PmxVecEnv:
         arr = states if isinstance(states, C.Array) else (_lib.State * count)(*states)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.pmx_set_state(self.handle, first, count, arr, self._stream()), "pmx_set_state")
+
+    def layout_indices(self):
+        """The layout of the pool each env is on right now (int32 numpy array [n_envs])."""
+        out = np.zeros(self.n_envs, np.int32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.pmx_get_layout_index(self.handle, out.ctypes.data_as(C.POINTER(C.c_int32)), self._stream()),
+                       "pmx_get_layout_index")
+        return out
 
     def maze_distances(self, layout=0):
         """distanceCalculator.computeDistances for a layout -> (cells [n,2] int8, dist [n,n] uint8) on the GPU."""

@@ -444,6 +444,65 @@ def test_one_distinct_maze_per_env_vs_oracle():
     env.close()
 
 
+def _redraw_index(seed, env, ticks, n):
+    """include/pmx.h redraw_layouts: the counter-based draw, restated in Python."""
+    M = 0xFFFFFFFF
+    x = ((seed ^ ((env * 0x9E3779B1) & M)) ^ ((ticks * 0x85EBCA77) & M) ^ 0x4C41594F) & M
+    x ^= x >> 16; x = (x * 0x7FEB352D) & M; x ^= x >> 15; x = (x * 0x846CA68B) & M; x ^= x >> 16
+    return (x * n) >> 32
+
+
+def test_layout_redrawn_at_every_reset_vs_oracle():
+    """random_layout=True (gymPacMan.py:98-100: a new maze at every reset()): a pool of 40 generated mazes, 640 envs, short
+    episodes with in-kernel bots on both sides (thousands of auto-resets, each moving the env to a freshly drawn maze of the
+    pool) -- every output of every tick against the oracle, which draws with the same counter-based generator; then an
+    explicit masked pmx_reset against the generator restated in Python."""
+    pmx = _pmx()
+    from pmx import maze_generator as MG
+    P, N, T, seed = 40, 640, 130, 21
+    rows = [MG.generate_maze(100 + k).split("\n") for k in range(P)]
+    lays = [pmx.Layout.from_text(r) for r in rows]
+    index = (np.arange(N) % P).astype(np.int32)
+    env = pmx.PmxVecEnv(lays, N, length=14, auto_reset=True, obs_dtype="uint8", seed=seed, layout_index=index, redraw_layouts=True)
+    orc = O.MultiBatchEnv(rows, index.copy(), length=14, auto_reset=True, seed=seed, redraw=True)
+    env.reset()
+    assert not (env.layout_indices() == index).all()             # reset() itself draws (gymPacMan.reset does)
+    exp0 = np.array([_redraw_index(seed, e, 0, P) for e in range(N)], np.int32)
+    assert (env.layout_indices() == exp0).all()
+    # bring the oracle to the same starting point: its constructor reset does not redraw, so rebuild it on the drawn layouts
+    orc = O.MultiBatchEnv(rows, exp0.copy(), length=14, auto_reset=True, seed=seed, redraw=True)
+    oobs = np.zeros((N, 4, 8, 20, 20), np.float32)
+    rng = np.random.RandomState(8)
+    moved = 0
+    for t in range(T):
+        a = rng.randint(0, 5, size=(N, 4)).astype(np.int8)
+        a[rng.rand(N, 4) < 0.6] = -2
+        before = orc.index.copy()
+        orc.tick(a, oobs)
+        moved += int((before != orc.index).sum())
+        obs, rew, done, info = env.step(torch.tensor(a).cuda())
+        assert rew.cpu().numpy().tobytes() == orc.reward.tobytes(), t
+        assert (done.cpu().numpy() == orc.done).all() and (info["legal_actions"].cpu().numpy() == orc.legal).all(), t
+        bad = np.nonzero((obs.cpu().numpy() != oobs.astype(np.uint8)).reshape(N, -1).any(1))[0]
+        assert len(bad) == 0, f"t={t}: obs differ for envs {bad[:8]}"
+        if t % 15 == 14:
+            assert (env.layout_indices() == orc.index).all(), t
+    assert moved > 4 * N and len(set(orc.index.tolist())) > P // 2   # each env changed maze several times, the pool is used
+    # explicit reset of a subset: those envs draw with their current tick counter, the others keep their maze
+    cur = env.layout_indices()
+    ticks = np.array([s.ticks for s in env.get_state(0, N)], np.uint32)
+    mask = torch.zeros(N, dtype=torch.uint8, device="cuda")
+    mask[::3] = 1
+    env.reset(mask)
+    new = env.layout_indices()
+    for e in range(N):
+        want = _redraw_index(seed, e, int(ticks[e]), P) if e % 3 == 0 else cur[e]
+        assert new[e] == want, e
+    with pytest.raises(ValueError):
+        pmx.PmxVecEnv(lays[0], 8, redraw_layouts=True)
+    env.close()
+
+
 _TINY_BOARD = ["%%%%%%%%", "%1 .. 2%", "%  ..  %", "%3 .. 4%", "%%%%%%%%"]
 
 

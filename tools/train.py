@@ -13,6 +13,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--layout", default="smallCapture", help='a layout name, or "mazes": one distinct generated 20x20 maze per env (BASELINE config 5)')
+ap.add_argument("--redraw", action="store_true", help="with --layout mazes: every reset moves the env to a freshly drawn maze of the pool "
+                                                      "(the reference's random_layout=True, gymPacMan.py:98-100)")
 ap.add_argument("--log", default="", help="append the per-update JSON lines to this file as well (tools/plot_log.py plots it)")
 ap.add_argument("--envs", type=int, default=16384, help="envs per GPU")
 ap.add_argument("--horizon", type=int, default=32)
@@ -56,7 +58,7 @@ def emit(rec):
             fh.write(line + "\n")
 
 
-tr = trainer.VecMAPPOTrainer(layout, args.envs, horizon=args.horizon, minibatch=args.minibatch, epochs=args.epochs,
+tr = trainer.VecMAPPOTrainer(layout, args.envs, horizon=args.horizon, minibatch=args.minibatch, epochs=args.epochs, redraw_layouts=args.redraw,
                              obs_dtype=args.obs, device=f"cuda:{local}", seed=args.seed, rank=rank, world_size=world,
                              total_updates=args.total_updates, opponent=args.opponent, algorithm=args.algorithm, use_graph=args.graph, paired_minibatches=not args.unpaired, flat_bf16=args.flat_bf16, curriculum_scale=args.curriculum_scale)
 for u in range(args.updates):
