@@ -443,7 +443,7 @@ __device__ __forceinline__ void store_env(const Env &e, const Ctx &c, uint32_t *
     st[(size_t)PMX_W_TICKS(c.H) * N + env] = e.ticks;
 }
 // random_layout=True (gymPacMan.py:98-100): the layout an env moves to when it is reset; counter-based draw keyed by
-// (seed, env, the env's tick counter), reproduced by the oracle (orc_redraw_layout)
+// (seed, env, the env's tick counter) -- a build-side definition, include/pmx.h redraw_layouts
 __device__ __forceinline__ int redraw_layout(uint32_t key, uint32_t ticks, int n_layouts)
 {
     uint32_t x = key ^ (ticks * 0x85EBCA77u) ^ 0x4C41594Fu;
