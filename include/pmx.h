@@ -303,6 +303,25 @@ int pmx_ffn_forward(const void *x_dev, const void *pack_dev, void *y_dev, int64_
 int pmx_ffn_backward(const void *x_dev, const void *dy_dev, const void *pack_dev, void *dx_dev, float *grad_dev, int64_t tokens,
                      float eps, void *stream);
 
+/* The other token-parallel pieces of the encoder layer (nn.MultiheadAttention's packed in-projection and its out-projection
+ * followed by the residual add and norm1), same kernel scheme, [tokens][32] bfloat16 inputs:
+ *   tok96:    qkv [tokens][96] = in_proj_weight [96][32] a + in_proj_bias
+ *   tok32ln:  y [tokens][32]  = LayerNorm(x + out_proj.weight [32][32] a + out_proj.bias)
+ * Backward returns da (and dx = the gradient of the residual input) and zeroes + sums grad_dev:
+ *   tok96:   dW [96][32], db [96]                  (+ 64 unused floats)
+ *   tok32ln: dW [32][32], db [32], dgamma [32], dbeta [32] */
+#define PMX_TOK96_PACK_BYTES 12928
+#define PMX_TOK96_GRAD_FLOATS 3232
+#define PMX_TOK32_PACK_BYTES 4480
+#define PMX_TOK32_GRAD_FLOATS 1120
+int pmx_tok96_pack(const float *w, const float *b, void *pack_dev, void *stream);
+int pmx_tok96_forward(const void *a_dev, const void *pack_dev, void *y_dev, int64_t tokens, void *stream);
+int pmx_tok96_backward(const void *a_dev, const void *dy_dev, const void *pack_dev, void *da_dev, float *grad_dev, int64_t tokens, void *stream);
+int pmx_tok32ln_pack(const float *w, const float *b, const float *gamma, const float *beta, void *pack_dev, void *stream);
+int pmx_tok32ln_forward(const void *x_dev, const void *a_dev, const void *pack_dev, void *y_dev, int64_t tokens, float eps, void *stream);
+int pmx_tok32ln_backward(const void *x_dev, const void *a_dev, const void *dy_dev, const void *pack_dev, void *dx_dev, void *da_dev,
+                         float *grad_dev, int64_t tokens, float eps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,8 @@ ACTOR_PACK_BYTES = 297984
 ACTOR_GRAD_FLOATS = 74496
 FFN_PACK_BYTES = 33664
 FFN_GRAD_FLOATS = 8416
+TOK96_PACK_BYTES, TOK96_GRAD_FLOATS = 12928, 3232
+TOK32_PACK_BYTES, TOK32_GRAD_FLOATS = 4480, 1120
 
 
 class PmxError(RuntimeError):
@@ -91,6 +93,12 @@ PROTOTYPES = [
     ("pmx_ffn_pack", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     ("pmx_ffn_forward", C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_float, _VP]),
     ("pmx_ffn_backward", C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_float, _VP]),
+    ("pmx_tok96_pack", C.c_int, [_VP, _VP, _VP, _VP]),
+    ("pmx_tok96_forward", C.c_int, [_VP, _VP, _VP, C.c_int64, _VP]),
+    ("pmx_tok96_backward", C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
+    ("pmx_tok32ln_pack", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    ("pmx_tok32ln_forward", C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_float, _VP]),
+    ("pmx_tok32ln_backward", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_float, _VP]),
 ]
 # test / bench hooks that are not part of the public header
 EXTRA = [

@@ -396,6 +396,276 @@ __global__ __launch_bounds__(256) void pmx_ffn_pack_kernel(const float *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Token-parallel linear layers with 32 input features, same scheme as above (features on the rows, tokens on the columns,
+// output rows in the order psi within every 32-feature block so that a lane owns 8 consecutive features):
+//     NP = 3, LN = false :  qkv = W a + b                      the attention in-projection (32 -> 96)
+//     NP = 1, LN = true  :  y = LayerNorm(x + W a + b)         the attention out-projection + residual + norm1
+// Backward (recomputing t = W a + b where LayerNorm needs it): da = W^T dt, dx = dz, dW += dt (x) a over tokens through the
+// same 32-token LDS staging + transposing reads, bias / LayerNorm-affine gradients by per-lane sums.
+// pack: A forward [2 NP] fragments, A backward [2][NP] fragments, then floats bias [32 NP], gamma [32], beta [32]
+// grad: dW [32 NP][32], db [32 NP], dgamma [32], dbeta [32]
+// ---------------------------------------------------------------------------------------------------------------
+template <int NP> struct TokPack {
+    static constexpr size_t A_FWD = 0, A_BWD = A_FWD + 2 * NP * FRAG * 2, FLT = A_BWD + 2 * NP * FRAG * 2;
+    static constexpr size_t BYTES = FLT + (32 * NP + 64) * 4;
+    static constexpr int G_W = 0, G_B = 32 * NP * 32, G_GAMMA = G_B + 32 * NP, G_BETA = G_GAMMA + 32, G_FLOATS = G_BETA + 32;
+};
+static_assert(TokPack<3>::BYTES == PMX_TOK96_PACK_BYTES && TokPack<1>::BYTES == PMX_TOK32_PACK_BYTES, "pmx.h pack sizes");
+static_assert(TokPack<3>::G_FLOATS == PMX_TOK96_GRAD_FLOATS && TokPack<1>::G_FLOATS == PMX_TOK32_GRAD_FLOATS, "pmx.h gradient sizes");
+
+template <int NP, bool LN>
+__global__ __launch_bounds__(256, 2) void pmx_tok_fwd_kernel(const uint4 *__restrict__ a, const uint4 *__restrict__ x, const char *__restrict__ pack,
+                                                            uint4 *__restrict__ y, long T, float eps)
+{
+    const int lane = threadIdx.x & 63, p = lane & 15, g = lane >> 4;
+    const long n_tiles = (T + 15) >> 4;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (long)gridDim.x * 4;
+    bf16x8 A[2 * NP];
+    const bf16x8 *af = reinterpret_cast<const bf16x8 *>(pack + TokPack<NP>::A_FWD);
+#pragma unroll
+    for (int m = 0; m < 2 * NP; ++m) A[m] = af[m * 64 + lane];
+    const float *pf = reinterpret_cast<const float *>(pack + TokPack<NP>::FLT);
+    float bias[NP][8], gamma[8], beta[8];
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bias[q][j] = pf[32 * q + 8 * g + j];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gamma[j] = pf[32 * NP + 8 * g + j], beta[j] = pf[32 * NP + 32 + 8 * g + j];
+    auto fetch = [&](const uint4 *src, long tile) -> uint4 {
+        const long tok = tile * 16 + p;
+        return (tile < n_tiles && tok < T) ? src[tok * 4 + g] : uint4{0, 0, 0, 0};
+    };
+    uint4 a0 = fetch(a, wave), a1 = fetch(a, wave + n_waves);
+    uint4 x0 = LN ? fetch(x, wave) : uint4{0, 0, 0, 0}, x1 = LN ? fetch(x, wave + n_waves) : uint4{0, 0, 0, 0};
+    for (long tile = wave; tile < n_tiles; tile += n_waves) {
+        const uint4 a2 = fetch(a, tile + 2 * n_waves);
+        const uint4 x2 = LN ? fetch(x, tile + 2 * n_waves) : uint4{0, 0, 0, 0};
+        const bf16x8 B0 = __builtin_bit_cast(bf16x8, a0);
+        const long tok = tile * 16 + p;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            f32x4 c0 = {bias[q][0], bias[q][1], bias[q][2], bias[q][3]}, c1 = {bias[q][4], bias[q][5], bias[q][6], bias[q][7]};
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2 * q], B0, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2 * q + 1], B0, c1, 0, 0, 0);
+            float o[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+            if (LN) {
+                const float xv[8] = {lo_f(x0.x), hi_f(x0.x), lo_f(x0.y), hi_f(x0.y), lo_f(x0.z), hi_f(x0.z), lo_f(x0.w), hi_f(x0.w)};
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += xv[j], s1 += o[j];
+                const float mean = token_sum(s1) * (1.0f / 32.0f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] -= mean, s2 = fmaf(o[j], o[j], s2);
+                const float rstd = __builtin_amdgcn_rsqf(token_sum(s2) * (1.0f / 32.0f) + eps);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = fmaf(o[j] * rstd, gamma[j], beta[j]);
+            }
+            if (tok < T) y[tok * (4 * NP) + 4 * q + g] = uint4{pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
+        }
+        a0 = a1, a1 = a2, x0 = x1, x1 = x2;
+    }
+}
+
+template <int NP> constexpr int tok_stg_row() { return (32 + 32 * NP) * 2 + 16; }
+
+template <int NP>
+__device__ __forceinline__ bf16x8 tok_tr_frag(const char *stg, int col_byte, int lane)
+{
+    const int g = lane >> 4, row = (lane & 15) >> 2, pc = lane & 3;
+    const char *a0 = stg + (8 * g + row) * tok_stg_row<NP>() + col_byte + pc * 8;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)(a0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)(a0 + 4 * tok_stg_row<NP>()));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int NP, bool LN>
+__global__ __launch_bounds__(256, 2) void pmx_tok_bwd_kernel(const uint4 *__restrict__ a, const uint4 *__restrict__ x, const uint4 *__restrict__ dy,
+                                                            const char *__restrict__ pack, uint4 *__restrict__ da, uint4 *__restrict__ dx,
+                                                            float *__restrict__ grad, long T, float eps)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROW = tok_stg_row<NP>();
+    const int lane = threadIdx.x & 63, p = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    char *stg = smem + (size_t)wv * 32 * ROW;
+    const long n_pairs = (T + 31) >> 5;
+    const long wave = (long)blockIdx.x * 4 + wv, n_waves = (long)gridDim.x * 4;
+    bf16x8 A[2 * NP], At[2][NP];
+    {
+        const bf16x8 *af = reinterpret_cast<const bf16x8 *>(pack + TokPack<NP>::A_FWD), *ab = reinterpret_cast<const bf16x8 *>(pack + TokPack<NP>::A_BWD);
+#pragma unroll
+        for (int m = 0; m < 2 * NP; ++m) A[m] = af[m * 64 + lane];
+#pragma unroll
+        for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) At[mo][q] = ab[(mo * NP + q) * 64 + lane];
+    }
+    const float *pf = reinterpret_cast<const float *>(pack + TokPack<NP>::FLT);
+    float bias[NP][8], gamma[8];
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bias[q][j] = pf[32 * q + 8 * g + j];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gamma[j] = pf[32 * NP + 8 * g + j];
+    f32x4 aw[2 * NP][2];
+#pragma unroll
+    for (int m = 0; m < 2 * NP; ++m) aw[m][0] = aw[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float db[NP][8], dgam[8], dbet[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        dgam[j] = dbet[j] = 0.f;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) db[q][j] = 0.f;
+    }
+    auto fetch = [&](const uint4 *src, long pair, int u, int chunks, int chunk) -> uint4 {
+        const long tok = pair * 32 + 16 * u + p;
+        return (pair < n_pairs && tok < T) ? src[tok * chunks + chunk] : uint4{0, 0, 0, 0};
+    };
+    for (long pair = wave; pair < n_pairs; pair += n_waves) {
+        uint4 av[2], xv4[2], dv[2][NP];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            av[u] = fetch(a, pair, u, 4, g);
+            xv4[u] = LN ? fetch(x, pair, u, 4, g) : uint4{0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < NP; ++q) dv[u][q] = fetch(dy, pair, u, 4 * NP, 4 * q + g);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            uint4 dt[NP];
+            if (LN) {
+                // recompute z = x + W a + b and its statistics, then LayerNorm's backward
+                const bf16x8 B0 = __builtin_bit_cast(bf16x8, av[u]);
+                f32x4 c0 = {bias[0][0], bias[0][1], bias[0][2], bias[0][3]}, c1 = {bias[0][4], bias[0][5], bias[0][6], bias[0][7]};
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B0, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1], B0, c1, 0, 0, 0);
+                const uint4 xb = xv4[u];
+                const float xf[8] = {lo_f(xb.x), hi_f(xb.x), lo_f(xb.y), hi_f(xb.y), lo_f(xb.z), hi_f(xb.z), lo_f(xb.w), hi_f(xb.w)};
+                float z[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) z[j] += xf[j], s1 += z[j];
+                const float mean = token_sum(s1) * (1.0f / 32.0f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) z[j] -= mean, s2 = fmaf(z[j], z[j], s2);
+                const float rstd = __builtin_amdgcn_rsqf(token_sum(s2) * (1.0f / 32.0f) + eps);
+                const uint4 db4 = dv[u][0];
+                const float d[8] = {lo_f(db4.x), hi_f(db4.x), lo_f(db4.y), hi_f(db4.y), lo_f(db4.z), hi_f(db4.z), lo_f(db4.w), hi_f(db4.w)};
+                float gd[8], t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = z[j] * rstd;
+                    z[j] = xh;
+                    dbet[j] += d[j];
+                    dgam[j] = fmaf(d[j], xh, dgam[j]);
+                    gd[j] = gamma[j] * d[j];
+                    t1 += gd[j];
+                    t2 = fmaf(gd[j], xh, t2);
+                }
+                t1 = token_sum(t1) * (1.0f / 32.0f), t2 = token_sum(t2) * (1.0f / 32.0f);
+                float dz[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dz[j] = rstd * (gd[j] - t1 - z[j] * t2);
+                dt[0] = uint4{pack2(dz[0], dz[1]), pack2(dz[2], dz[3]), pack2(dz[4], dz[5]), pack2(dz[6], dz[7])};
+                const long tok = pair * 32 + 16 * u + p;
+                if (tok < T) dx[tok * 4 + g] = dt[0];
+            } else {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) dt[q] = dv[u][q];
+            }
+            // da = W^T dt
+            f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const bf16x8 Bd = __builtin_bit_cast(bf16x8, dt[q]);
+                e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(At[0][q], Bd, e0, 0, 0, 0);
+                e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(At[1][q], Bd, e1, 0, 0, 0);
+                const float v[8] = {lo_f(dt[q].x), hi_f(dt[q].x), lo_f(dt[q].y), hi_f(dt[q].y), lo_f(dt[q].z), hi_f(dt[q].z), lo_f(dt[q].w), hi_f(dt[q].w)};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) db[q][j] += v[j];
+            }
+            const long tok = pair * 32 + 16 * u + p;
+            if (tok < T) da[tok * 4 + g] = uint4{pack2(e0[0], e0[1]), pack2(e0[2], e0[3]), pack2(e1[0], e1[1]), pack2(e1[2], e1[3])};
+            char *row = stg + (16 * u + p) * ROW;
+            *reinterpret_cast<uint4 *>(row + 16 * g) = av[u];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<uint4 *>(row + 64 + 64 * q + 16 * g) = dt[q];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const bf16x8 Fa0 = tok_tr_frag<NP>(stg, 0, lane), Fa1 = tok_tr_frag<NP>(stg, 32, lane);
+#pragma unroll
+        for (int m = 0; m < 2 * NP; ++m) {
+            const bf16x8 Fd = tok_tr_frag<NP>(stg, 64 + 32 * m, lane);
+            aw[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fd, Fa0, aw[m][0], 0, 0, 0);      // dW[out 16m ..][in 0..15]
+            aw[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Fd, Fa1, aw[m][1], 0, 0, 0);      // dW[out 16m ..][in 16..31]
+        }
+    }
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem);           // 4 waves x 4 NP tiles x 1 KB
+#pragma unroll
+    for (int i = 0; i < 4 * NP; ++i) *reinterpret_cast<f32x4 *>(red + ((size_t)(wv * 4 * NP + i) * 64 + lane) * 4) = aw[i >> 1][i & 1];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4 * NP * 64; i += 256) {
+        f32x4 v = *reinterpret_cast<const f32x4 *>(red + (size_t)i * 4);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            const f32x4 u = *reinterpret_cast<const f32x4 *>(red + ((size_t)q * 4 * NP * 64 + i) * 4);
+            v[0] += u[0], v[1] += u[1], v[2] += u[2], v[3] += u[3];
+        }
+        const int t = i >> 6, l = i & 63, m = t >> 1, half = t & 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (v[r] != 0.f) atomicAdd(grad + TokPack<NP>::G_W + (16 * m + 4 * (l >> 4) + r) * 32 + 16 * half + (l & 15), v[r]);
+    }
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = tile_sum(db[q][j]);
+            if (p == 0 && v != 0.f) atomicAdd(grad + TokPack<NP>::G_B + 32 * q + 8 * g + j, v);
+        }
+    if (LN) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float b = tile_sum(dgam[j]), c = tile_sum(dbet[j]);
+            if (p == 0) {
+                if (b != 0.f) atomicAdd(grad + TokPack<NP>::G_GAMMA + 8 * g + j, b);
+                if (c != 0.f) atomicAdd(grad + TokPack<NP>::G_BETA + 8 * g + j, c);
+            }
+        }
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void pmx_tok_pack_kernel(const float *__restrict__ w, const float *__restrict__ b, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, char *__restrict__ pack)
+{
+    // w [32 NP][32] (nn.Linear weight)
+    short *af = reinterpret_cast<short *>(pack + TokPack<NP>::A_FWD), *ab = reinterpret_cast<short *>(pack + TokPack<NP>::A_BWD);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * NP * FRAG; i += gridDim.x * 256) {
+        const int j = i & 7, lane = (i >> 3) & 63, f = i >> 9;
+        const int row = lane & 15, g = lane >> 4;
+        const int psi_row = 8 * (row >> 2) + (row & 3);
+        // forward fragment f = 2 q + m': W[out 32 q + psi(m', row)][in 8 g + j]
+        af[i] = (short)(pack2(w[(32 * (f >> 1) + psi_row + 4 * (f & 1)) * 32 + 8 * g + j], 0.f) & 0xFFFF);
+        // backward fragment f = mo * NP + q: W[out 32 q + 8 g + j][in psi(mo, row)]
+        ab[i] = (short)(pack2(w[(32 * (f % NP) + 8 * g + j) * 32 + psi_row + 4 * (f / NP)], 0.f) & 0xFFFF);
+    }
+    if (blockIdx.x == 0) {
+        float *pf = reinterpret_cast<float *>(pack + TokPack<NP>::FLT);
+        for (int i = threadIdx.x; i < 32 * NP; i += 256) pf[i] = b[i];
+        if (threadIdx.x < 32) {
+            pf[32 * NP + threadIdx.x] = gamma ? gamma[threadIdx.x] : 1.f;
+            pf[32 * NP + 32 + threadIdx.x] = beta ? beta[threadIdx.x] : 0.f;
+        }
+    }
+}
+
 int cu_count()
 {
     int dev = 0, cus = 256;
@@ -447,4 +717,64 @@ extern "C" int pmx_ffn_backward(const void *x_dev, const void *dy_dev, const voi
     hipLaunchKernelGGL(pmx_ffn_bwd_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(256), lds, st, (const uint4 *)x_dev, (const uint4 *)dy_dev,
                        (const char *)pack_dev, (uint4 *)dx_dev, grad_dev, (long)tokens, eps);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
+
+namespace {
+template <int NP, bool LN>
+int tok_forward(const void *a, const void *x, const void *pack, void *y, int64_t tokens, float eps, hipStream_t st)
+{
+    if (tokens == 0) return PMX_OK;
+    if (!a || !pack || !y || (LN && !x) || tokens < 0) return PMX_ERR_INVALID;
+    const int64_t tiles = (tokens + 15) / 16, want = (tiles + 3) / 4, cap = (int64_t)cu_count() * 2;
+    hipLaunchKernelGGL((pmx_tok_fwd_kernel<NP, LN>), dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, st, (const uint4 *)a, (const uint4 *)x,
+                       (const char *)pack, (uint4 *)y, (long)tokens, eps);
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
+template <int NP, bool LN>
+int tok_backward(const void *a, const void *x, const void *dy, const void *pack, void *da, void *dx, float *grad, int64_t tokens, float eps,
+                 hipStream_t st)
+{
+    if (!grad) return PMX_ERR_INVALID;
+    if (hipMemsetAsync(grad, 0, sizeof(float) * TokPack<NP>::G_FLOATS, st) != hipSuccess) return PMX_ERR_HIP;
+    if (tokens == 0) return PMX_OK;
+    if (!a || !dy || !pack || !da || (LN && (!x || !dx)) || tokens < 0) return PMX_ERR_INVALID;
+    const size_t stage = (size_t)4 * 32 * tok_stg_row<NP>(), reduce = (size_t)4 * 4 * NP * 1024;   // staging areas, then the block-level sum
+    const size_t lds = stage > reduce ? stage : reduce;
+    const int64_t pairs = (tokens + 31) / 32, want = (pairs + 3) / 4, cap = (int64_t)cu_count() * 2;
+    hipLaunchKernelGGL((pmx_tok_bwd_kernel<NP, LN>), dim3((unsigned)(want < cap ? want : cap)), dim3(256), lds, st, (const uint4 *)a, (const uint4 *)x,
+                       (const uint4 *)dy, (const char *)pack, (uint4 *)da, (uint4 *)dx, grad, (long)tokens, eps);
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
+}   // namespace
+
+extern "C" int pmx_tok96_pack(const float *w, const float *b, void *pack_dev, void *stream)
+{
+    if (!w || !b || !pack_dev) return PMX_ERR_INVALID;
+    hipLaunchKernelGGL(pmx_tok_pack_kernel<3>, dim3(12), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, b, (const float *)nullptr,
+                       (const float *)nullptr, reinterpret_cast<char *>(pack_dev));
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
+extern "C" int pmx_tok96_forward(const void *a_dev, const void *pack_dev, void *y_dev, int64_t tokens, void *stream)
+{
+    return tok_forward<3, false>(a_dev, nullptr, pack_dev, y_dev, tokens, 0.f, reinterpret_cast<hipStream_t>(stream));
+}
+extern "C" int pmx_tok96_backward(const void *a_dev, const void *dy_dev, const void *pack_dev, void *da_dev, float *grad_dev, int64_t tokens, void *stream)
+{
+    return tok_backward<3, false>(a_dev, nullptr, dy_dev, pack_dev, da_dev, nullptr, grad_dev, tokens, 0.f, reinterpret_cast<hipStream_t>(stream));
+}
+extern "C" int pmx_tok32ln_pack(const float *w, const float *b, const float *gamma, const float *beta, void *pack_dev, void *stream)
+{
+    if (!w || !b || !gamma || !beta || !pack_dev) return PMX_ERR_INVALID;
+    hipLaunchKernelGGL(pmx_tok_pack_kernel<1>, dim3(4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, b, gamma, beta,
+                       reinterpret_cast<char *>(pack_dev));
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
+extern "C" int pmx_tok32ln_forward(const void *x_dev, const void *a_dev, const void *pack_dev, void *y_dev, int64_t tokens, float eps, void *stream)
+{
+    return tok_forward<1, true>(a_dev, x_dev, pack_dev, y_dev, tokens, eps, reinterpret_cast<hipStream_t>(stream));
+}
+extern "C" int pmx_tok32ln_backward(const void *x_dev, const void *a_dev, const void *dy_dev, const void *pack_dev, void *dx_dev, void *da_dev,
+                                    float *grad_dev, int64_t tokens, float eps, void *stream)
+{
+    return tok_backward<1, true>(a_dev, x_dev, dy_dev, pack_dev, da_dev, dx_dev, grad_dev, tokens, eps, reinterpret_cast<hipStream_t>(stream));
 }

@@ -121,6 +121,94 @@ class _FFNLayerNorm(torch.autograd.Function):
         return (dx,) + tuple(o.to(dt) for o, dt in zip(outs, ctx.dtypes)) + (None,)
 
 
+class _InProj96(torch.autograd.Function):
+    """qkv = in_proj_weight a + in_proj_bias on [..., 32] bfloat16 tokens (pmx_tok96_forward / _backward)."""
+
+    @staticmethod
+    def forward(ctx, a, w, b):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        a = a.contiguous()
+        st = C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+        wf, bf = w.detach().float().contiguous(), b.detach().float().contiguous()
+        pack = torch.empty(_lib.TOK96_PACK_BYTES, dtype=torch.uint8, device=a.device)
+        _lib.check(lib.pmx_tok96_pack(wf.data_ptr(), bf.data_ptr(), pack.data_ptr(), st), "pmx_tok96_pack")
+        y = torch.empty(a.shape[:-1] + (96,), dtype=torch.bfloat16, device=a.device)
+        _lib.check(lib.pmx_tok96_forward(a.data_ptr(), pack.data_ptr(), y.data_ptr(), a.numel() // 32, st), "pmx_tok96_forward")
+        ctx.save_for_backward(a, pack)
+        ctx.dtypes = (w.dtype, b.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        a, pack = ctx.saved_tensors
+        st = C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+        dy = dy.to(torch.bfloat16).contiguous()
+        da = torch.empty_like(a)
+        grad = torch.empty(_lib.TOK96_GRAD_FLOATS, dtype=torch.float32, device=a.device)
+        _lib.check(lib.pmx_tok96_backward(a.data_ptr(), dy.data_ptr(), pack.data_ptr(), da.data_ptr(), grad.data_ptr(), a.numel() // 32, st),
+                   "pmx_tok96_backward")
+        return da, grad[:3072].view(96, 32).to(ctx.dtypes[0]), grad[3072:3168].to(ctx.dtypes[1])
+
+
+class _OutProjAddLN(torch.autograd.Function):
+    """LayerNorm(x + out_proj.weight a + out_proj.bias) on [..., 32] bfloat16 tokens (pmx_tok32ln_forward / _backward)."""
+
+    @staticmethod
+    def forward(ctx, x, a, w, b, gamma, beta, eps):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        x, a = x.contiguous(), a.contiguous()
+        st = C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+        ps = [t.detach().float().contiguous() for t in (w, b, gamma, beta)]
+        pack = torch.empty(_lib.TOK32_PACK_BYTES, dtype=torch.uint8, device=a.device)
+        _lib.check(lib.pmx_tok32ln_pack(*[t.data_ptr() for t in ps], pack.data_ptr(), st), "pmx_tok32ln_pack")
+        y = torch.empty_like(x)
+        _lib.check(lib.pmx_tok32ln_forward(x.data_ptr(), a.data_ptr(), pack.data_ptr(), y.data_ptr(), x.numel() // 32, float(eps), st),
+                   "pmx_tok32ln_forward")
+        ctx.save_for_backward(x, a, pack)
+        ctx.eps = float(eps)
+        ctx.dtypes = [t.dtype for t in (w, b, gamma, beta)]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        x, a, pack = ctx.saved_tensors
+        st = C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+        dy = dy.to(torch.bfloat16).contiguous()
+        dx, da = torch.empty_like(x), torch.empty_like(a)
+        grad = torch.empty(_lib.TOK32_GRAD_FLOATS, dtype=torch.float32, device=a.device)
+        _lib.check(lib.pmx_tok32ln_backward(x.data_ptr(), a.data_ptr(), dy.data_ptr(), pack.data_ptr(), dx.data_ptr(), da.data_ptr(),
+                                            grad.data_ptr(), x.numel() // 32, ctx.eps, st), "pmx_tok32ln_backward")
+        outs = (grad[:1024].view(32, 32), grad[1024:1056], grad[1056:1088], grad[1088:1120])
+        return (dx, da) + tuple(o.to(dt) for o, dt in zip(outs, ctx.dtypes)) + (None,)
+
+
+def _fused_tokens_ok(x, *weights):
+    return (MAPPOAgent.fused_ffn and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] == 32
+            and all(w.dtype == torch.float32 for w in weights))
+
+
+def in_proj96(x, mha):
+    if _fused_tokens_ok(x, mha.in_proj_weight) and tuple(mha.in_proj_weight.shape) == (96, 32):
+        return _InProj96.apply(x, mha.in_proj_weight, mha.in_proj_bias)
+    return token_linear(x, mha.in_proj_weight, mha.in_proj_bias)
+
+
+def out_proj_add_layer_norm(x, a, proj, ln):
+    if _fused_tokens_ok(x, proj.weight) and a.dtype == torch.bfloat16 and tuple(proj.weight.shape) == (32, 32):
+        return _OutProjAddLN.apply(x, a, proj.weight, proj.bias, ln.weight, ln.bias, ln.eps)
+    return add_layer_norm_small(x, token_linear(a, proj.weight, proj.bias), ln)
+
+
 def ffn_layer_norm(x, lin1, lin2, ln):
     """The feed-forward half of the post-LN encoder layer: the fused HIP kernels for bf16 tokens of width 32 with a 128-wide
     hidden layer on the GPU, the separate ops otherwise."""
@@ -235,11 +323,12 @@ class CriticEncoderLayer(nn.TransformerEncoderLayer):
         S, B, E = x.shape
         mha = self.self_attn
         h, d = mha.num_heads, E // mha.num_heads
-        qkv = token_linear(x, mha.in_proj_weight, mha.in_proj_bias)
+        if x.is_cuda and torch.is_autocast_enabled() and x.dtype != torch.bfloat16:
+            x = x.to(torch.bfloat16)
+        qkv = in_proj96(x, mha) if (E == 32 and h == 4) else token_linear(x, mha.in_proj_weight, mha.in_proj_bias)
         if qkv.is_cuda and qkv.dtype == torch.bfloat16 and E == 32 and h == 4 and S <= (640 if torch.is_grad_enabled() else 1024):
             a = attention8(qkv) if torch.is_grad_enabled() else attention8_forward(qkv)   # hand-written MFMA attention
-            a = token_linear(a, mha.out_proj.weight, mha.out_proj.bias)
-            x = add_layer_norm_small(x, a, self.norm1)
+            x = out_proj_add_layer_norm(x, a, mha.out_proj, self.norm1)
             return ffn_layer_norm(x, self.linear1, self.linear2, self.norm2)
         q, k, v = qkv.chunk(3, dim=-1)
         q, k, v = (t.reshape(S, B * h, d).transpose(0, 1).reshape(B, h, S, d) for t in (q, k, v))
@@ -410,7 +499,14 @@ class MAPPOAgent(nn.Module):
                 feat = actor_tower.tower_forward(obs, self.tower_pack)
             else:
                 feat = actor_tower.actor_tower(self.actor_backbone, obs)         # [B, H*W, 32] bf16
-            return self.actor_head(feat.permute(0, 2, 1).reshape(feat.shape[0], -1))
+            # nn.Flatten's order is (channel, cell), the kernel's is (cell, channel): permute the 5 MB weight of the first
+            # head layer instead of the features (160 MB per 16 384 samples, forward and again backward); autograd carries the
+            # gradient back through the view
+            lin = self.actor_head[0]
+            HW = feat.shape[1]
+            w = lin.weight.view(lin.out_features, 32, HW).permute(0, 2, 1).reshape(lin.out_features, HW * 32)
+            h = F.linear(feat.reshape(feat.shape[0], HW * 32), w, lin.bias)
+            return self.actor_head[1:](h)
         if obs.dtype == torch.uint8:            # byte planes are an input format of the fused tower only
             obs = obs.to(torch.bfloat16 if (obs.is_cuda and torch.is_autocast_enabled()) else torch.float32)
         if obs.is_cuda and obs.dtype == torch.bfloat16 and obs.dim() == 4:

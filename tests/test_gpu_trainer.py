@@ -455,3 +455,43 @@ def test_fused_ffn_layernorm_matches_torch(tokens):
         assert a.shape == b.shape
         rel = ((a.detach().cpu().double() - b).norm() / (b.norm() + 1e-12)).item()
         assert rel < 2e-2, (tuple(a.shape), rel)
+
+
+@pytest.mark.parametrize("tokens", [154 * 48, 37, 32 * 129 + 16])
+def test_fused_in_projection_and_out_projection_layernorm_match_torch(tokens):
+    """pmx_tok96_* (qkv = W a + b) and pmx_tok32ln_* (LayerNorm(x + W a + b)) against a float64 CPU reference on the
+    bf16-rounded operands: outputs within 2 bf16 ulps of the output scale, all gradients within 2e-2 relative (Frobenius)."""
+    from pmx import mappo
+    torch.manual_seed(5)
+    mha = torch.nn.MultiheadAttention(32, 4).cuda()
+    ln = torch.nn.LayerNorm(32).cuda()
+    with torch.no_grad():
+        mha.in_proj_bias.normal_(0, 0.3); mha.out_proj.bias.normal_(0, 0.3)
+        ln.weight.add_(0.2 * torch.randn_like(ln.weight)); ln.bias.add_(0.2 * torch.randn_like(ln.bias))
+    rb = lambda t: t + (t.float().to(torch.bfloat16).to(t.dtype) - t).detach()
+    x = torch.randn(tokens, 32, device="cuda").to(torch.bfloat16).requires_grad_(True)
+    a = torch.randn(tokens, 32, device="cuda").to(torch.bfloat16).requires_grad_(True)
+    # in-projection
+    dq = (0.1 * torch.randn(tokens, 96, device="cuda")).to(torch.bfloat16)
+    qkv = mappo.in_proj96(x, mha)
+    assert qkv.shape == (tokens, 96) and qkv.dtype == torch.bfloat16
+    got = torch.autograd.grad(qkv, [x, mha.in_proj_weight, mha.in_proj_bias], dq)
+    xc = x.detach().cpu().double().requires_grad_(True)
+    wc, bc = mha.in_proj_weight.detach().cpu().double().requires_grad_(True), mha.in_proj_bias.detach().cpu().double().requires_grad_(True)
+    qc = xc @ rb(wc).T + bc
+    want = torch.autograd.grad(qc, [xc, wc, bc], dq.cpu().double())
+    assert (qkv.detach().cpu().double() - qc.detach()).abs().max().item() <= 2 * 2 ** -8 * max(1.0, qc.abs().max().item())
+    for g_, w_ in zip(got, want):
+        assert ((g_.detach().cpu().double() - w_).norm() / (w_.norm() + 1e-12)).item() < 2e-2, tuple(w_.shape)
+    # out-projection + residual + LayerNorm
+    dy = (0.1 * torch.randn(tokens, 32, device="cuda")).to(torch.bfloat16)
+    y = mappo.out_proj_add_layer_norm(x, a, mha.out_proj, ln)
+    params = [mha.out_proj.weight, mha.out_proj.bias, ln.weight, ln.bias]
+    got = torch.autograd.grad(y, [x, a] + params, dy)
+    xc, ac = x.detach().cpu().double().requires_grad_(True), a.detach().cpu().double().requires_grad_(True)
+    pc = [p.detach().cpu().double().requires_grad_(True) for p in params]
+    yc = torch.nn.functional.layer_norm(xc + ac @ rb(pc[0]).T + pc[1], (32,), pc[2], pc[3], ln.eps)
+    want = torch.autograd.grad(yc, [xc, ac] + pc, dy.cpu().double())
+    assert (y.detach().cpu().double() - yc.detach()).abs().max().item() <= 2 * 2 ** -8 * max(1.0, yc.abs().max().item())
+    for g_, w_ in zip(got, want):
+        assert ((g_.detach().cpu().double() - w_).norm() / (w_.norm() + 1e-12)).item() < 2e-2, tuple(w_.shape)
