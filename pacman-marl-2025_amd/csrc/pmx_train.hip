@@ -2,6 +2,7 @@
 // post-processing.  C-ABI entry points for pmx_gae / pmx_canonicalize_obs / pmx_merge_obs live here too.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 
 #include <hip/hip_bf16.h>
 
@@ -749,6 +750,10 @@ extern "C" int pmx_attn8_forward(const void *qkv_dev, void *out_dev, float *lse_
 // the row-major operands of the score products are read straight from global memory (16 bytes per lane, L1-resident).
 // Gradients are written in the packed [S][B][96] layout of the in-projection output.
 // ---------------------------------------------------------------------------------------------------------------
+// NPF > 0: the sequence has exactly NPF pairs of 16-row tiles and each wave keeps ITS row operands (K and V rows for the dQ
+// pass, Q and dO rows for the dK/dV pass) in registers for all of its tiles instead of re-reading them from global memory
+// once per tile (10x for S = 154): 16 NPF registers, loaded once.
+template <int NPF>
 __global__ __launch_bounds__(512) void pmx_attn8_bwd_kernel(const __hip_bfloat16 *__restrict__ qkv, const __hip_bfloat16 *__restrict__ outp,
                                                             const __hip_bfloat16 *__restrict__ dout, const float *__restrict__ lse,
                                                             __hip_bfloat16 *__restrict__ dqkv, int S, int B, float scale)
@@ -819,7 +824,44 @@ __global__ __launch_bounds__(512) void pmx_attn8_bwd_kernel(const __hip_bfloat16
     };
 
     // ---- pass A: dQ
-    if (role == 0)
+    if (NPF > 0 && role == 0) {
+        pmx_bf16x8 kr[NPF > 0 ? 2 * NPF : 1], vr[NPF > 0 ? 2 * NPF : 1];
+#pragma unroll
+        for (int t = 0; t < 2 * NPF; ++t) {
+            kr[t] = row8(base, row_stride, head_off + E, t * 16 + c);
+            vr[t] = row8(base, row_stride, head_off + 2 * E, t * 16 + c);
+        }
+        for (int qt = 0; qt < n_t; ++qt) {
+            const int q_row = qt * 16 + c;
+            const pmx_bf16x8 qf = row8(base, row_stride, head_off, q_row);
+            const pmx_bf16x8 dof = row8(dobase, orow, ohead, q_row);
+            const float ls = fmaxf(lse_s[q_row < S_pad ? q_row : 0], -120.f), dl = delta_s[q_row < S_pad ? q_row : 0];
+            pmx_f32x4 dq = z4;
+#pragma unroll
+            for (int kp = 0; kp < NPF; ++kp) {
+                const pmx_f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kr[2 * kp], qf, z4, 0, 0, 0);
+                const pmx_f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kr[2 * kp + 1], qf, z4, 0, 0, 0);
+                const pmx_f32x4 p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vr[2 * kp], dof, z4, 0, 0, 0);
+                const pmx_f32x4 p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vr[2 * kp + 1], dof, z4, 0, 0, 0);
+                pmx_bf16x8 dsf;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c2, -ls));
+                    const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c2, -ls));
+                    dsf[r] = pmx_f2bf(e0 * (p0[r] - dl));
+                    dsf[4 + r] = pmx_f2bf(e1 * (p1[r] - dl));
+                }
+                dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Kt, kp), dsf, dq, 0, 0, 0);
+            }
+            if (q_row < S && g < 2) {
+                short w4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w4[r] = pmx_f2bf(dq[r] * scale);
+                *reinterpret_cast<uint2 *>(dbase + (size_t)q_row * row_stride + head_off + g * 4) = *reinterpret_cast<const uint2 *>(w4);
+            }
+        }
+    }
+    if (NPF == 0 && role == 0)
     for (int qt = 0; qt < n_t; ++qt) {
         const int q_row = qt * 16 + c;
         const pmx_bf16x8 qf = row8(base, row_stride, head_off, q_row);
@@ -860,7 +902,47 @@ __global__ __launch_bounds__(512) void pmx_attn8_bwd_kernel(const __hip_bfloat16
         }
     }
     // ---- pass B: dK, dV
-    if (role == 1)
+    if (NPF > 0 && role == 1) {
+        pmx_bf16x8 qr[NPF > 0 ? 2 * NPF : 1], dr[NPF > 0 ? 2 * NPF : 1];
+#pragma unroll
+        for (int t = 0; t < 2 * NPF; ++t) {
+            qr[t] = row8(base, row_stride, head_off, t * 16 + c);
+            dr[t] = row8(dobase, orow, ohead, t * 16 + c);
+        }
+        for (int kt = 0; kt < n_t; ++kt) {
+            const int k_row = kt * 16 + c;
+            const pmx_bf16x8 kf = row8(base, row_stride, head_off + E, k_row);
+            const pmx_bf16x8 vf = row8(base, row_stride, head_off + 2 * E, k_row);
+            pmx_f32x4 dk = z4, dv = z4;
+#pragma unroll
+            for (int qp = 0; qp < NPF; ++qp) {
+                const pmx_f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[2 * qp], kf, z4, 0, 0, 0);
+                const pmx_f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[2 * qp + 1], kf, z4, 0, 0, 0);
+                const pmx_f32x4 p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dr[2 * qp], vf, z4, 0, 0, 0);
+                const pmx_f32x4 p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dr[2 * qp + 1], vf, z4, 0, 0, 0);
+                pmx_bf16x8 pf, dsf;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qa = qp * 32 + g * 4 + r, qb = qa + 16;
+                    const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c2, -lse_s[qa]));
+                    const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c2, -lse_s[qb]));
+                    pf[r] = pmx_f2bf(e0); pf[4 + r] = pmx_f2bf(e1);
+                    dsf[r] = pmx_f2bf(e0 * (p0[r] - delta_s[qa]));
+                    dsf[4 + r] = pmx_f2bf(e1 * (p1[r] - delta_s[qb]));
+                }
+                dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(dOt, qp), pf, dv, 0, 0, 0);
+                dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Qt, qp), dsf, dk, 0, 0, 0);
+            }
+            if (k_row < S && g < 2) {
+                short wk[4], wv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { wk[r] = pmx_f2bf(dk[r] * scale); wv[r] = pmx_f2bf(dv[r]); }
+                *reinterpret_cast<uint2 *>(dbase + (size_t)k_row * row_stride + head_off + E + g * 4) = *reinterpret_cast<const uint2 *>(wk);
+                *reinterpret_cast<uint2 *>(dbase + (size_t)k_row * row_stride + head_off + 2 * E + g * 4) = *reinterpret_cast<const uint2 *>(wv);
+            }
+        }
+    }
+    if (NPF == 0 && role == 1)
     for (int kt = 0; kt < n_t; ++kt) {
         const int k_row = kt * 16 + c;
         const pmx_bf16x8 kf = row8(base, row_stride, head_off + E, k_row);
@@ -917,12 +999,17 @@ extern "C" int pmx_attn8_backward(const void *qkv_dev, const void *out_dev, cons
     if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev < 0 || cur_dev >= 64) return PMX_ERR_HIP;
     bool &attr_set = attr_set_dev[cur_dev];
     if (lds > 65536 && !attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(pmx_attn8_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(pmx_attn8_bwd_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return PMX_ERR_HIP;
         attr_set = true;
     }
-    hipLaunchKernelGGL(pmx_attn8_bwd_kernel, dim3(B), dim3(512), lds, st, (const __hip_bfloat16 *)qkv_dev, (const __hip_bfloat16 *)out_dev,
-                       (const __hip_bfloat16 *)dout_dev, lse_dev, (__hip_bfloat16 *)dqkv_dev, S, B, 0.35355339059327379f);
+    static const bool generic_only = getenv("PMX_ATTN_BWD_GENERIC") != nullptr;      // A/B switch, read once
+    if (S_pad == 160 && !generic_only)       // tinyCapture and smallCapture (154 cells): the row operands of a wave fit in 80 registers
+        hipLaunchKernelGGL(pmx_attn8_bwd_kernel<5>, dim3(B), dim3(512), lds, st, (const __hip_bfloat16 *)qkv_dev, (const __hip_bfloat16 *)out_dev,
+                           (const __hip_bfloat16 *)dout_dev, lse_dev, (__hip_bfloat16 *)dqkv_dev, S, B, 0.35355339059327379f);
+    else
+        hipLaunchKernelGGL(pmx_attn8_bwd_kernel<0>, dim3(B), dim3(512), lds, st, (const __hip_bfloat16 *)qkv_dev, (const __hip_bfloat16 *)out_dev,
+                           (const __hip_bfloat16 *)dout_dev, lse_dev, (__hip_bfloat16 *)dqkv_dev, S, B, 0.35355339059327379f);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
 

@@ -1,7 +1,7 @@
 import sys, os, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from pmx import mappo
-S, B = 154, 4096
+S, B = 154, int(os.environ.get("ATTN_B", 8192))
 qkv = (torch.randn(S, B, 96, device="cuda")).to(torch.bfloat16).requires_grad_(True)
 g = torch.randn(S, B, 32, device="cuda").to(torch.bfloat16)
 def t(fn, n=30):
