@@ -280,6 +280,7 @@ int pmx_create(const pmx_config *cfg, pmx_env **out)
         env->tune.nt = env_int("PMX_EXPAND_NT");
         env->tune.lds_pad = env_int("PMX_EXPAND_LDS_PAD");
         env->tune.lut = env_int("PMX_EXPAND_LUT");
+        env->tune.per_env = env_int("PMX_EXPAND_PER_ENV");
     }
     env->cfg.wall_rows = env->cfg.food_rows = env->cfg.cap_rows = nullptr;
     env->cfg.starts = nullptr;
@@ -469,6 +470,7 @@ int pmx_set_tuning(pmx_env *env, const char *key, int32_t value)
     else if (!strcmp(key, "expand_nt")) env->tune.nt = value;
     else if (!strcmp(key, "expand_lds_pad")) env->tune.lds_pad = value;
     else if (!strcmp(key, "expand_lut")) env->tune.lut = value;
+    else if (!strcmp(key, "expand_wave_per_env")) env->tune.per_env = value;
     else return fail(PMX_ERR_INVALID, "pmx_set_tuning: unknown key %s", key);
     return PMX_OK;
 }

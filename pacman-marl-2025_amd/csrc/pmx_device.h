@@ -105,4 +105,5 @@ struct PmxExpandTuning {
     int32_t nt = -1;             // non-temporal stores
     int32_t lds_pad = -1;        // dynamic-LDS reservation per block (occupancy cap), bytes
     int32_t lut = -1;            // LDS look-up-table expansion
+    int32_t per_env = -1;        // one wave per env (pmx_expand4_kernel) instead of one per (env, agent)
 };

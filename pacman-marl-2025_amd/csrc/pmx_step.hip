@@ -867,6 +867,122 @@ __global__ __launch_bounds__(PMX_BLOCK) void pmx_expand_kernel(PmxExpandParams p
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The same expansion with ONE wavefront per ENV for the narrow element types: at 1 or 2 bytes per element an (env, agent)
+// block is 1.2 - 2.5 KB, i.e. one or two store instructions per lane behind a fixed ~2 us of snapshot-load latency and table
+// set-up -- pmx_expand_kernel is issue / latency bound there (0.39 of the HBM peak for uint8).  Here a wave issues the snapshot
+// loads of all four agents together, builds the four bit streams side by side in LDS and then streams the env's whole
+// [4][8][H][W] block (4.9 KB of uint8 for smallCapture, contiguous: whole 128-byte lines except at the two ends, where
+// pmx_expand_kernel's 1 232-byte agent blocks split a line each).
+// ---------------------------------------------------------------------------------------------------------------
+template <int DT, bool NT>
+__global__ __launch_bounds__(PMX_BLOCK) void pmx_expand4_kernel(PmxExpandParams p)
+{
+    constexpr int VEC = ObsVec<DT>::VEC;
+    constexpr int TW = 8 * 32 * 32 / 32 + 8;
+    __shared__ uint32_t tab[4][4][TW];                        // [wave][agent][stream words]
+    __shared__ __align__(16) uint32_t lut[DT == 0 ? 16 * 4 : (DT == 1 ? 256 * 4 : 256 * 2)];
+    {
+        const uint32_t i = threadIdx.x;
+        if (DT == 0) {
+            if (i < 16) *reinterpret_cast<uint4 *>(&lut[4 * i]) = pack_obs<0>(i);
+        } else if (DT == 1) {
+            *reinterpret_cast<uint4 *>(&lut[4 * i]) = pack_obs<1>(i);
+        } else {
+            lut[2 * i] = ((i & 15u) * 0x00204081u) & 0x01010101u;
+            lut[2 * i + 1] = ((i >> 4) * 0x00204081u) & 0x01010101u;
+        }
+        __syncthreads();
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int W = p.lay_W, H = p.lay_H, HW = H * W;
+    long blk = p.reverse ? (long)gridDim.x - 1 - (long)blockIdx.x : (long)blockIdx.x;
+    if ((p.N & 127) == 0) {
+        // XCD-aware order (blocks b, b + 8, .. share an XCD): the 16 envs whose SoA snapshot words share a 64-byte line are the
+        // four blocks 4k .. 4k+3; send them to one XCD
+        const long r = blk & 31;
+        blk = (blk & ~31L) + ((r & 7) << 2) + (r >> 3);
+    }
+    const long env = blk * 4 + wave;
+    if (env >= p.N) return;
+    const size_t N = (size_t)p.N;
+    const PmxLayoutDev *L = p.lay + (p.layout_idx ? p.layout_idx[env] : 0);
+    // all four agents' snapshot words in flight together
+    uint32_t food[4], pt[4], a_self[4], b_self[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const uint32_t *S = p.snap[a] + env;
+        food[a] = lane < H ? S[(size_t)lane * N] : 0u;
+        pt[a] = 0;
+        if (lane < 4) pt[a] = S[(size_t)PMX_W_AGENT_A(H, lane) * N];
+        else if (lane < 8) pt[a] = S[(size_t)PMX_W_CAPS(H, (lane - 4) >> 1) * N];
+        a_self[a] = S[(size_t)PMX_W_AGENT_A(H, a) * N];
+        b_self[a] = S[(size_t)PMX_W_AGENT_B(H, a) * N];
+    }
+    const int n_words = (8 * HW + 31) >> 5;
+    const int wall_words = (HW + 31) >> 5;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+        for (int k = lane; k < n_words + 1; k += 64) tab[wave][a][k] = k < wall_words ? L->wall_stream[k] : 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int fself[4];
+    uint32_t carry[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        uint32_t *T = tab[wave][a];
+        if (lane < H) {
+            stream_or_row(T, (uint32_t)((6 * H + lane) * W), food[a] & L->hi_mask, W);
+            stream_or_row(T, (uint32_t)((7 * H + lane) * W), food[a] & L->lo_mask, W);
+        }
+        if (lane < 4) {
+            const int x = pt[a] & 0xFF, y = (pt[a] >> 8) & 0xFF;
+            const int plane = lane == a ? 1 : (((lane ^ a) == 2) ? 4 : 5);
+            const uint32_t off = (uint32_t)((plane * H + y) * W + x);
+            atomicOr(&T[off >> 5], 1u << (off & 31));
+        } else if (lane < 8) {
+            const uint32_t cxy = (pt[a] >> (16 * ((lane - 4) & 1))) & 0xFFFFu;
+            if (cxy != 0xFFFFu) {
+                const int x = cxy & 0xFF, y = cxy >> 8;
+                const int plane = (2 * x > W) ? 2 : 3;
+                const uint32_t off = (uint32_t)((plane * H + y) * W + x);
+                atomicOr(&T[off >> 5], 1u << (off & 31));
+            }
+        }
+        carry[a] = (b_self[a] >> 8) & 0xFFF;
+        fself[a] = (H + (int)((a_self[a] >> 8) & 0xFF)) * W + (int)(a_self[a] & 0xFF);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const int n_vec = 8 * HW / VEC;
+    uint4 *out = reinterpret_cast<uint4 *>(p.obs) + (size_t)env * 4 * n_vec;
+    for (int kk = lane; kk < 4 * n_vec; kk += 64) {
+        const int a = kk / n_vec, k = kk - a * n_vec;
+        const uint32_t e0 = (uint32_t)k * VEC;
+        const uint32_t bits = tab[wave][a][e0 >> 5] >> (e0 & 31);
+        uint4 v;
+        if (DT == 0) v = *reinterpret_cast<const uint4 *>(&lut[(bits & 15u) * 4]);
+        else if (DT == 1) v = *reinterpret_cast<const uint4 *>(&lut[(bits & 255u) * 4]);
+        else {
+            const uint2 lo = *reinterpret_cast<const uint2 *>(&lut[(bits & 255u) * 2]);
+            const uint2 hi = *reinterpret_cast<const uint2 *>(&lut[((bits >> 8) & 255u) * 2]);
+            v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+        const int fs = a == 0 ? fself[0] : (a == 1 ? fself[1] : (a == 2 ? fself[2] : fself[3]));
+        const uint32_t cr = a == 0 ? carry[0] : (a == 1 ? carry[1] : (a == 2 ? carry[2] : carry[3]));
+        const uint32_t d = (uint32_t)(fs - (int)e0);
+        if (d < (uint32_t)VEC) patch_self<DT>(v, (int)d, cr);
+        if (NT) {
+            __builtin_nontemporal_store(v.x, &out[kk].x); __builtin_nontemporal_store(v.y, &out[kk].y);
+            __builtin_nontemporal_store(v.z, &out[kk].z); __builtin_nontemporal_store(v.w, &out[kk].w);
+        } else {
+            out[kk] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Training-side emission: what the MAPPO rollout does with every tick's observations (pacman_mappo_resnet.py:462-469),
 // straight from the snapshots: the two learners' planes -- canonicalised for a red team (canonicalize_obs :215-229: x
 // flipped, capsule planes 2 <-> 3 and food planes 6 <-> 7 swapped) -- and merge_obs_for_critic (:267-274: the first
@@ -1092,6 +1208,31 @@ extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, const PmxExpan
     p = &q;
     bool use_lut = true;
     if (tune && tune->lut >= 0) use_lut = tune->lut != 0;                 // experiment override
+    // uint8 planes with all four agents emitted: one wave per env (pmx_expand4_kernel; measured at 16 384 envs of smallCapture:
+    // 25.8 -> 22.4 us for uint8, but 26.7 -> 28.3 us for bfloat16, which therefore keeps the wave per (env, agent));
+    // pmx_set_tuning("expand_wave_per_env", 0/1) overrides
+    bool per_env = dtype == 2 && p->n_emit == 4 && p->single_agent < 0;
+    if (tune && tune->per_env >= 0) per_env = tune->per_env != 0 && p->n_emit == 4 && p->single_agent < 0;
+    if (per_env) {
+        const unsigned b4 = (unsigned)((p->N + 3) / 4);
+#define PMX_EXPAND4(DT, NTV)                                                                                              \
+    do {                                                                                                                  \
+        if (ev0) hipExtLaunchKernelGGL((pmx_expand4_kernel<DT, NTV>), dim3(b4), dim3(PMX_BLOCK), 0, st, ev0, ev1, 0, *p);   \
+        else hipLaunchKernelGGL((pmx_expand4_kernel<DT, NTV>), dim3(b4), dim3(PMX_BLOCK), 0, st, *p);                      \
+    } while (0)
+        // the planes of these types fit the Infinity Cache up to a few hundred MB: ordinary stores there, streaming beyond
+        const bool nt4 = (tune && tune->nt >= 0) ? tune->nt != 0 : bytes > ((size_t)200 << 20);
+        PmxExpandParams q4 = *p;
+        if (nt4) q4.reverse = 0;
+        p = &q4;
+        switch (dtype) {
+        case 0: if (nt4) PMX_EXPAND4(0, true); else PMX_EXPAND4(0, false); break;
+        case 1: if (nt4) PMX_EXPAND4(1, true); else PMX_EXPAND4(1, false); break;
+        default: if (nt4) PMX_EXPAND4(2, true); else PMX_EXPAND4(2, false); break;
+        }
+#undef PMX_EXPAND4
+        return hipGetLastError();
+    }
 #define PMX_EXPAND_LAUNCH2(DT, NTV, LUTV)                                                                               \
     do {                                                                                                                \
         if (ev0) hipExtLaunchKernelGGL((pmx_expand_kernel<DT, NTV, LUTV>), dim3(blocks), dim3(PMX_BLOCK), (uint32_t)lds_pad, st, ev0, ev1, 0, *p); \
