@@ -192,8 +192,11 @@ def main():
     ap.add_argument("--envs", type=int, default=0, help="override envs per GPU")
     ap.add_argument("--obs", default="float32", choices=sorted(ELEM))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-unidirectional", action="store_true", help="skip the short comparison pass with PMX_EXPAND_ALT=0 (for profiler runs)")
+    ap.add_argument("--no-unidirectional", action="store_true", help="skip the pass with a consumer between ticks (for profiler runs)")
     ap.add_argument("--no-ppo", action="store_true", help="skip the short MAPPO rollout/update probe")
+    ap.add_argument("--fixed-sweep", action="store_true",
+                    help="run EVERY pass with the sweep direction fixed (all bytes to HBM): for profiler runs, so that the trace's average "
+                         "duration of the expansion kernel is the one `roofline` is quoted on")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -226,6 +229,8 @@ def main():
     dev = torch.device("cuda", local)
     env = pmx.PmxVecEnv(lay, n_envs, length=length, auto_reset=True, obs_dtype=args.obs, device=dev)
     env.reset()
+    if args.fixed_sweep:
+        env.set_tuning("expand_alt", 0)
     # the action stream: uniform over the 5 actions from the device Philox generator, resident before timing
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     n_act = 64
@@ -280,7 +285,7 @@ def main():
     for k in range(k_uni):
         env.step(actions[k % n_act])
     prof_uni = env.profile_end()
-    env.set_tuning("expand_alt", -1)
+    env.set_tuning("expand_alt", 0 if args.fixed_sweep else -1)
     prof_cons = None
     if not args.no_unidirectional:
         slots = torch.empty((4,) + tuple(env.obs.shape), dtype=env.obs.dtype, device=dev)

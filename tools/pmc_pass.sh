@@ -6,7 +6,7 @@ W=$1; O=$2; TAG=$3
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$c -- python3 $ROOT/bench.py --workload $W --obs $O --steps 40 --warmup 10 --no-cpu-baseline --no-ppo --no-unidirectional > /tmp/pmc_${TAG}_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$c -- python3 $ROOT/bench.py --workload $W --obs $O --steps 40 --warmup 10 --no-cpu-baseline --no-ppo --no-unidirectional --fixed-sweep > /tmp/pmc_${TAG}_$c.log 2>&1
 done
 cd $ROOT
 python tools/pmc_traffic.py /tmp/pmc_${TAG}_FETCH_SIZE /tmp/pmc_${TAG}_WRITE_SIZE $W:$O gpurun_out/traffic_new.json

@@ -14,7 +14,7 @@ import os
 import sys
 
 
-def per_launch(d, counter, kernel="pmx_expand_kernel"):
+def per_launch(d, counter, kernel="pmx_expand"):     # pmx_expand_kernel and pmx_expand4_kernel
     vals = []
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
