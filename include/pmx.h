@@ -294,12 +294,16 @@ int pmx_actor_unpack_grads(const float *grad_dev, const pmx_actor_params *out, v
  * nn.TransformerEncoderLayer(d_model 32, dim_feedforward 128, ReLU, dropout 0, norm_first False), pacman_mappo_resnet.py:138-141:
  *   y = LayerNorm(x + linear2(relu(linear1(x))))   on [tokens][32] bfloat16 rows, fp32 accumulation and LayerNorm.
  * Parameters are float32 device pointers with nn.Module shapes (linear1.weight [128][32], linear2.weight [32][128], norm2). */
+/* The backward kernels of this family sum their parameter gradients in two stages (a partial row per workgroup, then a row sum;
+ * float atomics from every workgroup onto the same few thousand addresses are an order of magnitude slower): grad_dev must
+ * hold (1 + PMX_GRAD_PARTIAL_ROWS) rows of *_GRAD_FLOATS floats; the result is row 0. */
+#define PMX_GRAD_PARTIAL_ROWS 512
 #define PMX_FFN_PACK_BYTES 33664
 #define PMX_FFN_GRAD_FLOATS 8416      /* dW2 [32][128], dW1 [128][32], db1 [128], db2 [32], dgamma [32], dbeta [32] */
 int pmx_ffn_pack(const float *w1, const float *b1, const float *w2, const float *b2, const float *gamma, const float *beta,
                  void *pack_dev, void *stream);
 int pmx_ffn_forward(const void *x_dev, const void *pack_dev, void *y_dev, int64_t tokens, float eps, void *stream);
-/* recomputes the forward from x (nothing is saved): dx_dev [tokens][32] bfloat16, grad_dev [PMX_FFN_GRAD_FLOATS] zeroed and summed here */
+/* recomputes the forward from x (nothing is saved): dx_dev [tokens][32] bfloat16, grad_dev [1 + PMX_GRAD_PARTIAL_ROWS][PMX_FFN_GRAD_FLOATS] (row 0 = result) */
 int pmx_ffn_backward(const void *x_dev, const void *dy_dev, const void *pack_dev, void *dx_dev, float *grad_dev, int64_t tokens,
                      float eps, void *stream);
 
@@ -307,7 +311,8 @@ int pmx_ffn_backward(const void *x_dev, const void *dy_dev, const void *pack_dev
  * followed by the residual add and norm1), same kernel scheme, [tokens][32] bfloat16 inputs:
  *   tok96:    qkv [tokens][96] = in_proj_weight [96][32] a + in_proj_bias
  *   tok32ln:  y [tokens][32]  = LayerNorm(x + out_proj.weight [32][32] a + out_proj.bias)
- * Backward returns da (and dx = the gradient of the residual input) and zeroes + sums grad_dev:
+ * Backward returns da (and dx = the gradient of the residual input) and the parameter gradients in row 0 of grad_dev
+ * [1 + PMX_GRAD_PARTIAL_ROWS][*_GRAD_FLOATS]:
  *   tok96:   dW [96][32], db [96]                  (+ 64 unused floats)
  *   tok32ln: dW [32][32], db [32], dgamma [32], dbeta [32] */
 #define PMX_TOK96_PACK_BYTES 12928

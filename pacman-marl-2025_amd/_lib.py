@@ -14,6 +14,7 @@ COLSUM_BLOCKS = 512
 LN32_PARTIAL_ROWS = 2048
 ACTOR_PACK_BYTES = 297984
 ACTOR_GRAD_FLOATS = 74496
+GRAD_PARTIAL_ROWS = 512
 FFN_PACK_BYTES = 33664
 FFN_GRAD_FLOATS = 8416
 TOK96_PACK_BYTES, TOK96_GRAD_FLOATS = 12928, 3232

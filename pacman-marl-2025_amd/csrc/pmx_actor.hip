@@ -336,7 +336,7 @@ template <int NT>
 __global__ __launch_bounds__(256, 1) void pmx_actor_bwd_data_kernel(const char *__restrict__ pack, const uint2 *__restrict__ dfeat,
                                                                    const uint2 *__restrict__ hsave, const uint2 *__restrict__ ysave,
                                                                    const float *__restrict__ stats, bf16x8 *__restrict__ dasave,
-                                                                   uint2 *__restrict__ sktmp, float *__restrict__ grad, int B, int H,
+                                                                   uint2 *__restrict__ sktmp, float *__restrict__ accpart, int B, int H,
                                                                    int W)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -554,14 +554,32 @@ __global__ __launch_bounds__(256, 1) void pmx_actor_bwd_data_kernel(const char *
             wave_lds_fence();
         }
     }
-    if (any) {
-        wave_lds_fence();
-        for (int i = lane; i < NLAYER * 96; i += 64) {
-            const int l = i / 96, j = i - l * 96, kind = j >> 5, ch = j & 31;
-            const float v = acc[i];
-            if (v != 0.0f) atomicAdd(grad + (kind == 0 ? GRAD_B : kind == 1 ? GRAD_GNW : GRAD_GNB) + l * 32 + ch, v);
-        }
+    // the block's four waves' sums -> one partial row per block (plain stores; a second tiny kernel adds the rows: float
+    // atomics from 2 048 waves onto these 768 addresses would run at the rate of one contended row)
+    (void)any;
+    __syncthreads();
+    for (int i = threadIdx.x; i < NLAYER * 96; i += 256) {
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += reinterpret_cast<const float *>(smem + (size_t)w * (G.MP * 64 + NLAYER * 96 * 4) + (size_t)G.MP * 64)[i];
+        accpart[(size_t)blockIdx.x * (NLAYER * 96) + i] = v;
     }
+}
+
+// bias / GroupNorm-affine gradients: sum of the data kernel's per-block rows into the gradient buffer
+__global__ __launch_bounds__(256) void pmx_actor_sum_acc_kernel(const float *__restrict__ accpart, int n_rows, float *__restrict__ grad)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= NLAYER * 96) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int r = 0;
+    for (; r + 4 <= n_rows; r += 4) {
+        a0 += accpart[(size_t)r * (NLAYER * 96) + i], a1 += accpart[(size_t)(r + 1) * (NLAYER * 96) + i];
+        a2 += accpart[(size_t)(r + 2) * (NLAYER * 96) + i], a3 += accpart[(size_t)(r + 3) * (NLAYER * 96) + i];
+    }
+    for (; r < n_rows; ++r) a0 += accpart[(size_t)r * (NLAYER * 96) + i];
+    const int l = i / 96, j = i - l * 96, kind = j >> 5, ch = j & 31;
+    grad[(kind == 0 ? GRAD_B : kind == 1 ? GRAD_GNW : GRAD_GNB) + l * 32 + ch] = (a0 + a1) + (a2 + a3);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -745,7 +763,7 @@ extern "C" int pmx_actor_sizes(int32_t H, int32_t W, int64_t B, int64_t *save_by
     if (save_bytes) *save_bytes = B * (8 * dump + 8 * dump + 8 * 4 * 2 * 4);
     if (scratch_bytes) {
         const int64_t infer = 2048 * dump;                                     // inference: one skip-input slot per resident wave
-        const int64_t bwd = B * 8 * (int64_t)((tiles_for(H, W) + 1) / 2) * 2048 + infer; // backward: dH operand fragments of the 8 layers + skip slots
+        const int64_t bwd = B * 8 * (int64_t)((tiles_for(H, W) + 1) / 2) * 2048 + infer + 1024 * 768 * 4; // backward: dH operand fragments of the 8 layers + skip slots + partial sums
         *scratch_bytes = infer > bwd ? infer : bwd;
     }
     return PMX_OK;
@@ -840,11 +858,14 @@ int launch_bwd(const void *obs, const void *pack, const void *save, const void *
     const float *stt = reinterpret_cast<const float *>(ys + 8 * B * dump);
     bf16x8 *da = reinterpret_cast<bf16x8 *>(scratch);                       // [8][B][KS * 2][64] operand fragments of dH
     uint2 *sk = reinterpret_cast<uint2 *>(da + (size_t)8 * B * KS * 2 * 64);  // then one skip-gradient slot per resident wave
+    float *accpart = reinterpret_cast<float *>(sk + (size_t)2048 * dump);       // then the data kernel's per-block partial sums
     const size_t lds_d = (size_t)4 * (mp * 64 + NLAYER * 96 * 4);
     int rc = allow_lds(pmx_actor_bwd_data_kernel<NT>, lds_d);
     if (rc) return rc;
-    hipLaunchKernelGGL((pmx_actor_bwd_data_kernel<NT>), dim3(grid_for(B, 2)), dim3(256), lds_d, st, (const char *)pack, (const uint2 *)dfeat,
-                       hs, ys, stt, da, sk, grad, (int)B, H, W);
+    const int grid_d = grid_for(B, 2);
+    hipLaunchKernelGGL((pmx_actor_bwd_data_kernel<NT>), dim3(grid_d), dim3(256), lds_d, st, (const char *)pack, (const uint2 *)dfeat,
+                       hs, ys, stt, da, sk, accpart, (int)B, H, W);
+    hipLaunchKernelGGL(pmx_actor_sum_acc_kernel, dim3(3), dim3(256), 0, st, (const float *)accpart, grid_d, grad);
     if (hipGetLastError() != hipSuccess) return PMX_ERR_HIP;
     // weight gradient: layers x sample chunks; about two blocks per CU in total, each wave at least a few samples
     const size_t lds_w = (size_t)4 * mp * 64;

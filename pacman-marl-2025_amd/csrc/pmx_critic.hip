@@ -317,8 +317,12 @@ __global__ __launch_bounds__(256, 1) void pmx_ffn_bwd_kernel(const uint4 *__rest
             }
         }
     }
-    // ---- reductions: block-level sum of the 32 weight-gradient tiles through LDS, per-channel sums through shuffles ----
+    // ---- reductions: block-level sums through LDS; every block then writes ITS partial gradient row (plain stores) and a
+    // second tiny kernel adds the rows up.  Float atomics from every block onto the same 8 416 addresses ran at the rate of
+    // one contended row (MI355X_MICROARCH.md, global float atomics): ~90 us per call whatever the batch, which made the
+    // 512-sample optimizer step slower than the unfused path. ----
     __syncthreads();
+    float *mine = grad + (size_t)(1 + blockIdx.x) * G_FLOATS;
     float *red = reinterpret_cast<float *>(smem);           // 4 waves x 8 tiles x 1 KB = 32 KB per round (the staging areas are 80 KB)
 #pragma unroll
     for (int round = 0; round < 4; ++round) {
@@ -340,29 +344,44 @@ __global__ __launch_bounds__(256, 1) void pmx_ffn_bwd_kernel(const uint4 *__rest
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int rowi = 4 * rg + r;
-                float *dst = round < 2 ? grad + G_W2 + (16 * round + rowi) * 128 + 16 * t + col          // dW2[out][hidden]
-                                       : grad + G_W1 + (16 * t + rowi) * 32 + 16 * (round - 2) + col;    // dW1[hidden][in]
-                if (v[r] != 0.f) atomicAdd(dst, v[r]);
+                float *dst = round < 2 ? mine + G_W2 + (16 * round + rowi) * 128 + 16 * t + col          // dW2[out][hidden]
+                                       : mine + G_W1 + (16 * t + rowi) * 32 + 16 * (round - 2) + col;    // dW1[hidden][in]
+                *dst = v[r];
             }
         }
         __syncthreads();
     }
+    // per-channel sums: over the tile's tokens by shuffles, over the block's four waves through LDS
+    float *chan = red + (size_t)wv * 224;
 #pragma unroll
     for (int m = 0; m < 8; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float v = tile_sum(db1[m][r]);
-            if (p == 0 && v != 0.f) atomicAdd(grad + G_B1 + 16 * m + 4 * g + r, v);
+            if (p == 0) chan[16 * m + 4 * g + r] = v;
         }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float a = tile_sum(db2[j]), b = tile_sum(dgam[j]), c = tile_sum(dbet[j]);
-        if (p == 0) {
-            if (a != 0.f) atomicAdd(grad + G_B2 + 8 * g + j, a);
-            if (b != 0.f) atomicAdd(grad + G_GAMMA + 8 * g + j, b);
-            if (c != 0.f) atomicAdd(grad + G_BETA + 8 * g + j, c);
-        }
+        if (p == 0) chan[128 + 8 * g + j] = a, chan[160 + 8 * g + j] = b, chan[192 + 8 * g + j] = c;
     }
+    __syncthreads();
+    if (threadIdx.x < 224) mine[G_B1 + threadIdx.x] = red[threadIdx.x] + red[224 + threadIdx.x] + red[448 + threadIdx.x] + red[672 + threadIdx.x];
+}
+
+// out[i] = sum over the partial rows (rows 1 .. n of the same buffer): the second stage of the gradient reductions
+__global__ __launch_bounds__(256) void pmx_sum_rows_kernel(float *__restrict__ buf, int n_rows, int floats)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= floats) return;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int r = 1;
+    for (; r + 8 <= n_rows + 1; r += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += buf[(size_t)(r + k) * floats + i];
+    }
+    for (; r <= n_rows; ++r) acc[0] += buf[(size_t)r * floats + i];
+    buf[i] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -606,6 +625,7 @@ __global__ __launch_bounds__(256, 2) void pmx_tok_bwd_kernel(const uint4 *__rest
         }
     }
     __syncthreads();
+    float *mine = grad + (size_t)(1 + blockIdx.x) * TokPack<NP>::G_FLOATS;        // this block's partial row (see pmx_ffn_bwd_kernel)
     float *red = reinterpret_cast<float *>(smem);           // 4 waves x 4 NP tiles x 1 KB
 #pragma unroll
     for (int i = 0; i < 4 * NP; ++i) *reinterpret_cast<f32x4 *>(red + ((size_t)(wv * 4 * NP + i) * 64 + lane) * 4) = aw[i >> 1][i & 1];
@@ -619,26 +639,25 @@ __global__ __launch_bounds__(256, 2) void pmx_tok_bwd_kernel(const uint4 *__rest
         }
         const int t = i >> 6, l = i & 63, m = t >> 1, half = t & 1;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (v[r] != 0.f) atomicAdd(grad + TokPack<NP>::G_W + (16 * m + 4 * (l >> 4) + r) * 32 + 16 * half + (l & 15), v[r]);
+        for (int r = 0; r < 4; ++r) mine[TokPack<NP>::G_W + (16 * m + 4 * (l >> 4) + r) * 32 + 16 * half + (l & 15)] = v[r];
     }
+    __syncthreads();
+    constexpr int NCH = 32 * NP + 64;
+    float *chan = red + (size_t)wv * NCH;
 #pragma unroll
     for (int q = 0; q < NP; ++q)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float v = tile_sum(db[q][j]);
-            if (p == 0 && v != 0.f) atomicAdd(grad + TokPack<NP>::G_B + 32 * q + 8 * g + j, v);
+            if (p == 0) chan[32 * q + 8 * g + j] = v;
         }
-    if (LN) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float b = tile_sum(dgam[j]), c = tile_sum(dbet[j]);
-            if (p == 0) {
-                if (b != 0.f) atomicAdd(grad + TokPack<NP>::G_GAMMA + 8 * g + j, b);
-                if (c != 0.f) atomicAdd(grad + TokPack<NP>::G_BETA + 8 * g + j, c);
-            }
-        }
+    for (int j = 0; j < 8; ++j) {
+        const float b = tile_sum(dgam[j]), c = tile_sum(dbet[j]);
+        if (p == 0) chan[32 * NP + 8 * g + j] = b, chan[32 * NP + 32 + 8 * g + j] = c;
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NCH; i += 256) mine[TokPack<NP>::G_B + i] = red[i] + red[NCH + i] + red[2 * NCH + i] + red[3 * NCH + i];
 }
 
 template <int NP>
@@ -700,8 +719,7 @@ extern "C" int pmx_ffn_backward(const void *x_dev, const void *dy_dev, const voi
 {
     if (!grad_dev) return PMX_ERR_INVALID;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(grad_dev, 0, sizeof(float) * G_FLOATS, st) != hipSuccess) return PMX_ERR_HIP;
-    if (tokens == 0) return PMX_OK;
+    if (tokens == 0) return hipMemsetAsync(grad_dev, 0, sizeof(float) * G_FLOATS, st) == hipSuccess ? PMX_OK : PMX_ERR_HIP;
     if (!x_dev || !dy_dev || !pack_dev || !dx_dev || tokens < 0) return PMX_ERR_INVALID;
     const size_t lds = (size_t)4 * 32 * STG_ROW;
     static bool attr_dev[64] = {};
@@ -713,9 +731,12 @@ extern "C" int pmx_ffn_backward(const void *x_dev, const void *dy_dev, const voi
         attr_dev[dev] = true;
     }
     const int64_t pairs = (tokens + 31) / 32;
-    const int64_t want = (pairs + 3) / 4, cap = (int64_t)cu_count();
-    hipLaunchKernelGGL(pmx_ffn_bwd_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(256), lds, st, (const uint4 *)x_dev, (const uint4 *)dy_dev,
+    int64_t want = (pairs + 3) / 4, cap = (int64_t)cu_count();
+    if (cap > PMX_GRAD_PARTIAL_ROWS) cap = PMX_GRAD_PARTIAL_ROWS;
+    const unsigned blocks = (unsigned)(want < cap ? want : cap);
+    hipLaunchKernelGGL(pmx_ffn_bwd_kernel, dim3(blocks), dim3(256), lds, st, (const uint4 *)x_dev, (const uint4 *)dy_dev,
                        (const char *)pack_dev, (uint4 *)dx_dev, grad_dev, (long)tokens, eps);
+    hipLaunchKernelGGL(pmx_sum_rows_kernel, dim3((G_FLOATS + 255) / 256), dim3(256), 0, st, grad_dev, (int)blocks, (int)G_FLOATS);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
 
@@ -735,14 +756,16 @@ int tok_backward(const void *a, const void *x, const void *dy, const void *pack,
                  hipStream_t st)
 {
     if (!grad) return PMX_ERR_INVALID;
-    if (hipMemsetAsync(grad, 0, sizeof(float) * TokPack<NP>::G_FLOATS, st) != hipSuccess) return PMX_ERR_HIP;
-    if (tokens == 0) return PMX_OK;
+    if (tokens == 0) return hipMemsetAsync(grad, 0, sizeof(float) * TokPack<NP>::G_FLOATS, st) == hipSuccess ? PMX_OK : PMX_ERR_HIP;
     if (!a || !dy || !pack || !da || (LN && (!x || !dx)) || tokens < 0) return PMX_ERR_INVALID;
-    const size_t stage = (size_t)4 * 32 * tok_stg_row<NP>(), reduce = (size_t)4 * 4 * NP * 1024;   // staging areas, then the block-level sum
+    const size_t stage = (size_t)4 * 32 * tok_stg_row<NP>(), reduce = (size_t)4 * 4 * NP * 1024 + 4096;   // staging areas, then the block-level sums
     const size_t lds = stage > reduce ? stage : reduce;
-    const int64_t pairs = (tokens + 31) / 32, want = (pairs + 3) / 4, cap = (int64_t)cu_count() * 2;
-    hipLaunchKernelGGL((pmx_tok_bwd_kernel<NP, LN>), dim3((unsigned)(want < cap ? want : cap)), dim3(256), lds, st, (const uint4 *)a, (const uint4 *)x,
+    int64_t pairs = (tokens + 31) / 32, want = (pairs + 3) / 4, cap = (int64_t)cu_count() * 2;
+    if (cap > PMX_GRAD_PARTIAL_ROWS) cap = PMX_GRAD_PARTIAL_ROWS;
+    const unsigned blocks = (unsigned)(want < cap ? want : cap);
+    hipLaunchKernelGGL((pmx_tok_bwd_kernel<NP, LN>), dim3(blocks), dim3(256), lds, st, (const uint4 *)a, (const uint4 *)x,
                        (const uint4 *)dy, (const char *)pack, (uint4 *)da, (uint4 *)dx, grad, (long)tokens, eps);
+    hipLaunchKernelGGL(pmx_sum_rows_kernel, dim3((TokPack<NP>::G_FLOATS + 255) / 256), dim3(256), 0, st, grad, (int)blocks, (int)TokPack<NP>::G_FLOATS);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
 }   // namespace

@@ -112,7 +112,7 @@ class _FFNLayerNorm(torch.autograd.Function):
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         dy = dy.to(torch.bfloat16).contiguous()
         dx = torch.empty_like(x)
-        grad = torch.empty(_lib.FFN_GRAD_FLOATS, dtype=torch.float32, device=dev)
+        grad = torch.empty((1 + _lib.GRAD_PARTIAL_ROWS) * _lib.FFN_GRAD_FLOATS, dtype=torch.float32, device=dev)   # row 0 = the result
         _lib.check(lib.pmx_ffn_backward(x.data_ptr(), dy.data_ptr(), pack.data_ptr(), dx.data_ptr(), grad.data_ptr(), x.numel() // 32,
                                         ctx.eps, st), "pmx_ffn_backward")
         dw2, dw1 = grad[:4096].view(32, 128), grad[4096:8192].view(128, 32)
@@ -149,7 +149,7 @@ class _InProj96(torch.autograd.Function):
         st = C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
         dy = dy.to(torch.bfloat16).contiguous()
         da = torch.empty_like(a)
-        grad = torch.empty(_lib.TOK96_GRAD_FLOATS, dtype=torch.float32, device=a.device)
+        grad = torch.empty((1 + _lib.GRAD_PARTIAL_ROWS) * _lib.TOK96_GRAD_FLOATS, dtype=torch.float32, device=a.device)
         _lib.check(lib.pmx_tok96_backward(a.data_ptr(), dy.data_ptr(), pack.data_ptr(), da.data_ptr(), grad.data_ptr(), a.numel() // 32, st),
                    "pmx_tok96_backward")
         return da, grad[:3072].view(96, 32).to(ctx.dtypes[0]), grad[3072:3168].to(ctx.dtypes[1])
@@ -185,7 +185,7 @@ class _OutProjAddLN(torch.autograd.Function):
         st = C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
         dy = dy.to(torch.bfloat16).contiguous()
         dx, da = torch.empty_like(x), torch.empty_like(a)
-        grad = torch.empty(_lib.TOK32_GRAD_FLOATS, dtype=torch.float32, device=a.device)
+        grad = torch.empty((1 + _lib.GRAD_PARTIAL_ROWS) * _lib.TOK32_GRAD_FLOATS, dtype=torch.float32, device=a.device)
         _lib.check(lib.pmx_tok32ln_backward(x.data_ptr(), a.data_ptr(), dy.data_ptr(), pack.data_ptr(), dx.data_ptr(), da.data_ptr(),
                                             grad.data_ptr(), x.numel() // 32, ctx.eps, st), "pmx_tok32ln_backward")
         outs = (grad[:1024].view(32, 32), grad[1024:1056], grad[1056:1088], grad[1088:1120])
