@@ -62,7 +62,10 @@ static_assert(GRAD_FLOATS == PMX_ACTOR_GRAD_FLOATS, "include/pmx.h and pmx_actor
 __host__ __device__ constexpr int map_positions(int nt, int wp) { return GUARD + wp + 32 * ((nt + 1) / 2) + wp + 3; }
 
 // byte offset of 16-byte chunk `chunk` (channels 8*chunk .. +7) of map position `pos`
-__device__ __forceinline__ int map_off(int pos, int chunk) { return pos * 64 + ((chunk ^ ((pos >> 1) & 2)) << 4); }
+// (No bank swizzle: an XOR of the chunk with bit 2 of the position makes the ds_read_b128 of an operand conflict-free, but costs
+// six vector-ALU instructions of address arithmetic per read, and these kernels are bound by their vector ALU, not by the
+// LDS -- 8-16 % busy with the swizzle.  Plain addresses are 2-way conflicted on that read and leave the address one add.)
+__device__ __forceinline__ int map_off(int pos, int chunk) { return pos * 64 + (chunk << 4); }
 
 __device__ __forceinline__ uint32_t pack2(float a, float b)
 {
@@ -163,20 +166,22 @@ __device__ __forceinline__ void load_frags(bf16x8 (&A)[2][9], const short *__res
         for (int k = 0; k < 9; ++k) A[m][k] = *reinterpret_cast<const bf16x8 *>(frag + ((m * 9 + k) * 64 + lane) * 8);
 }
 
-// One tile of the 3x3 convolution: 9 taps x 2 output halves on the map.  q0p = padded index of the lane's position + GUARD.
-__device__ __forceinline__ void conv_tile(const char *map, const bf16x8 (&A)[2][9], int q0p, int g, int WP, f32x4 &a0, f32x4 &a1)
+// One tile of the 3x3 convolution: 9 taps x 2 output halves on the map.  lane_base = map + (p + GUARD) * 64 + g * 16 (the lane's
+// part of every operand address), centre = byte offset of the tile's first position (wave-uniform), wp64 = (W + 2) * 64.
+__device__ __forceinline__ void conv_tile(const char *lane_base, const bf16x8 (&A)[2][9], int centre, int wp64, f32x4 &a0, f32x4 &a1)
 {
     a0 = f32x4{0.f, 0.f, 0.f, 0.f};
     a1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+    for (int ky = 0; ky < 3; ++ky) {
+        const char *row = lane_base + (centre + (ky - 1) * wp64 - 64);       // the three taps of a row are 64 bytes apart
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const int pos = q0p + (ky - 1) * WP + (kx - 1);
-            const bf16x8 b = *reinterpret_cast<const bf16x8 *>(map + map_off(pos, g));
+            const bf16x8 b = *reinterpret_cast<const bf16x8 *>(row + kx * 64);
             a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][ky * 3 + kx], b, a0, 0, 0, 0);
             a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1][ky * 3 + kx], b, a1, 0, 0, 0);
         }
+    }
 }
 
 // P-layout dump: 8 bytes per lane per (tile, half); a sample is NT * 2 * 512 bytes
@@ -185,6 +190,9 @@ __device__ __forceinline__ size_t dump_index(size_t sample, int NT, int t, int m
 // ---------------------------------------------------------------------------------------------------------------
 // Forward
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef PMX_ACTOR_RD
+#define PMX_ACTOR_RD 4                                        // tiles of residual in flight ahead of pass 2
+#endif
 template <int NT, typename IN_T, bool SAVE>
 __global__ __launch_bounds__(256, 2) void pmx_actor_fwd_kernel(const IN_T *__restrict__ obs, const char *__restrict__ pack,
                                                               uint2 *__restrict__ feat, uint2 *__restrict__ hsave,
@@ -249,10 +257,12 @@ __global__ __launch_bounds__(256, 2) void pmx_actor_fwd_kernel(const IN_T *__res
                 for (int r = 0; r < 4; ++r) bias[m][r] = biasp[l * 32 + 16 * m + 4 * g + r];
             uint2 hp[NT][2];                               // bf16-rounded convolution output (+ bias), packed
             float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+            const char *rbase = map + pq * 64 + g * 16;    // the lane's part of every operand read address
+            char *wbase = map + pq * 64 + g * 8;           // ... and of every P-layout write (chunk 2m + (g >> 1), half g & 1)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 f32x4 a[2];
-                conv_tile(map, A, WPv + 16 * t + pq, g, WPv, a[0], a[1]);
+                conv_tile(rbase, A, (WPv + 16 * t) * 64, WPv * 64, a[0], a[1]);
                 const float vm = ((vmk >> t) & 1) ? 1.0f : 0.0f;
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
@@ -272,6 +282,25 @@ __global__ __launch_bounds__(256, 2) void pmx_actor_fwd_kernel(const IN_T *__res
             }
             // the map has been read for the last time in this layer: the next layer's weights can start to arrive
             load_frags(A, fws + (size_t)(l + 1 < NLAYER ? l + 1 : l) * FRAG_PER_LAYER, lane);
+            // ... and so can everything pass 2 reads from global memory: the affine parameters and the whole residual (the block
+            // input of two layers back), RD tiles ahead of their use.  Issued here, the latency hides behind the statistics;
+            // loaded tile by tile inside pass 2 each of the 2 NT reads was a full round trip the wave sat out (half the
+            // kernel's time at two waves per SIMD).
+            constexpr int RD = PMX_ACTOR_RD;
+            float gw[2][4], gb[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gw[m][r] = gnwp[l * 32 + 16 * m + 4 * g + r], gb[m][r] = gnbp[l * 32 + 16 * m + 4 * g + r];
+            uint2 rres[NT][2];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) rres[t][0] = rres[t][1] = uint2{0u, 0u};
+            if (res_on) {
+#pragma unroll
+                for (int t = 0; t < RD; ++t)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) rres[t][m] = rsrc[(t * 2 + m) * 64];
+            }
             float mean[2], rstd[2];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -286,21 +315,18 @@ __global__ __launch_bounds__(256, 2) void pmx_actor_fwd_kernel(const IN_T *__res
                     st[0] = mean[m], st[1] = rstd[m];
                 }
             }
-            float gw[2][4], gb[2][4];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gw[m][r] = gnwp[l * 32 + 16 * m + 4 * g + r], gb[m][r] = gnbp[l * 32 + 16 * m + 4 * g + r];
             wave_lds_fence();
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const float vm = ((vmk >> t) & 1) ? 1.0f : 0.0f;
-                const int pos = WPv + 16 * t + pq;
+                if (t + RD < NT && res_on) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) rres[t + RD][m] = rsrc[((t + RD) * 2 + m) * 64];
+                }
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const uint2 r2 = rsrc[(t * 2 + m) * 64];
                     const float hv[4] = {lo_f(hp[t][m].x), hi_f(hp[t][m].x), lo_f(hp[t][m].y), hi_f(hp[t][m].y)};
-                    const uint32_t rx = res_on ? r2.x : 0u, ry = res_on ? r2.y : 0u;
+                    const uint32_t rx = rres[t][m].x, ry = rres[t][m].y;
                     const float rv[4] = {lo_f(rx), hi_f(rx), lo_f(ry), hi_f(ry)};
                     float v[4];
 #pragma unroll
@@ -309,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void pmx_actor_fwd_kernel(const IN_T *__res
                         v[r] = gelu_fast(z) * vm;
                     }
                     const uint2 y2 = {pack2(v[0], v[1]), pack2(v[2], v[3])};
-                    *reinterpret_cast<uint2 *>(map + map_off(pos, 2 * m + (g >> 1)) + (g & 1) * 8) = y2;
+                    *reinterpret_cast<uint2 *>(wbase + (WPv + 16 * t) * 64 + m * 32) = y2;
                     if (write_y) ydst[(t * 2 + m) * 64] = y2;
                     if (l == NLAYER - 1 && vm != 0.0f) {
                         const int q = WPv + 16 * t + p, row = q / WPv, col = q - row * WPv;
@@ -472,10 +498,10 @@ __global__ __launch_bounds__(256, 1) void pmx_actor_bwd_data_kernel(const char *
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dbias[m][r] = 0.0f;
+            char *wbase = map + pq * 64 + g * 8;            // the lane's part of every P-layout write address
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const float vm = ((vmk >> t) & 1) ? 1.0f : 0.0f;
-                const int pos = WPv + 16 * t + pq;
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     const uint2 h2 = hp[t][m];
@@ -490,7 +516,7 @@ __global__ __launch_bounds__(256, 1) void pmx_actor_bwd_data_kernel(const char *
                     const uint2 d2 = {pack2(dh[0], dh[1]), pack2(dh[2], dh[3])};
                     // the bias gradient sums what the matrix cores see (the bf16-rounded dh), like autograd on a bf16 tensor
                     dbias[m][0] += lo_f(d2.x), dbias[m][1] += hi_f(d2.x), dbias[m][2] += lo_f(d2.y), dbias[m][3] += hi_f(d2.y);
-                    *reinterpret_cast<uint2 *>(map + map_off(pos, 2 * m + (g >> 1)) + (g & 1) * 8) = d2;
+                    *reinterpret_cast<uint2 *>(wbase + (WPv + 16 * t) * 64 + m * 32) = d2;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -509,15 +535,14 @@ __global__ __launch_bounds__(256, 1) void pmx_actor_bwd_data_kernel(const char *
             // ---- dH in the weight-gradient kernel's operand layout: A[co][k = position], transposed out of the map --------
             {
                 bf16x8 *dst = dasave + (((size_t)l * B + s) * KS * 2) * 64 + lane;
+                const char *tbase = map + (8 * g + tr_row + GUARD) * 64 + tr_pc * 8;      // the lane's part of a transposing read
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const int qk = WPv + 32 * ks + 8 * g + tr_row + GUARD;
 #pragma unroll
                     for (int mo = 0; mo < 2; ++mo) {
-                        const int o0 = map_off(qk, 2 * mo + (tr_pc >> 1)) + (tr_pc & 1) * 8;
-                        const int o1 = map_off(qk + 4, 2 * mo + (tr_pc >> 1)) + (tr_pc & 1) * 8;
-                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)(map + o0));
-                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)(map + o1));
+                        const char *o0 = tbase + (WPv + 32 * ks) * 64 + mo * 32;
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)(o0));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)(o0 + 256));
                         dst[(ks * 2 + mo) * 64] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     }
                 }
@@ -537,7 +562,7 @@ __global__ __launch_bounds__(256, 1) void pmx_actor_bwd_data_kernel(const char *
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     f32x4 a[2];
-                    conv_tile(map, A, WPv + 16 * t + pq, g, WPv, a[0], a[1]);
+                    conv_tile(map + pq * 64 + g * 16, A, (WPv + 16 * t) * 64, WPv * 64, a[0], a[1]);
                     const float vm = ((vmk >> t) & 1) ? 1.0f : 0.0f;
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
@@ -627,25 +652,23 @@ __global__ __launch_bounds__(256, 2) void pmx_actor_bwd_weight_kernel(const IN_T
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
-                    *reinterpret_cast<uint2 *>(mapB + map_off(WPv + 16 * t + pq, 2 * m + (g >> 1)) + (g & 1) * 8) = xin[t][m];
+                    *reinterpret_cast<uint2 *>(mapB + pq * 64 + g * 8 + (WPv + 16 * t) * 64 + m * 32) = xin[t][m];
         }
         wave_lds_fence();
         const bf16x8 *asrc = dasave + (((size_t)l * B + s) * KS * 2) * 64 + lane;
 #pragma unroll 1
         for (int ks = 0; ks < KS; ++ks) {
-            const int qk = WPv + 32 * ks + 8 * g + tr_row + GUARD;
             const bf16x8 Ad0 = asrc[(ks * 2 + 0) * 64], Ad1 = asrc[(ks * 2 + 1) * 64];
+            const char *tbase = mapB + (8 * g + tr_row + GUARD) * 64 + tr_pc * 8 + (WPv + 32 * ks) * 64;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const int qx = qk + (ky - 1) * WPv + (kx - 1);
+                    const char *tx = tbase + ((ky - 1) * WPv + (kx - 1)) * 64;
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni) {
-                        const int o0 = map_off(qx, 2 * ni + (tr_pc >> 1)) + (tr_pc & 1) * 8;
-                        const int o1 = map_off(qx + 4, 2 * ni + (tr_pc >> 1)) + (tr_pc & 1) * 8;
-                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)(mapB + o0));
-                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)(mapB + o1));
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)(tx + ni * 32));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)(tx + ni * 32 + 256));
                         const bf16x8 Bx = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                         accw[(0 * 2 + ni) * 9 + ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ad0, Bx, accw[(0 * 2 + ni) * 9 + ky * 3 + kx], 0, 0, 0);
                         accw[(1 * 2 + ni) * 9 + ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ad1, Bx, accw[(1 * 2 + ni) * 9 + ky * 3 + kx], 0, 0, 0);
