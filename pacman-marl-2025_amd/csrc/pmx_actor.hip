@@ -190,8 +190,24 @@ __device__ __forceinline__ size_t dump_index(size_t sample, int NT, int t, int m
 // ---------------------------------------------------------------------------------------------------------------
 // Forward
 // ---------------------------------------------------------------------------------------------------------------
+// Forward-kernel tuning, measured on one box with tools/ab_build.sh / ab_run.sh (8 192 samples, training / inference variant):
+// RD 2 + late affine loads 605 / 615 us, RD 4 + early 625 / 650 us, RD 6 636 / 654 us -- past two tiles the registers a
+// deeper window costs (spills, each with an s_waitcnt vmcnt(0) that drains every store in flight) outweigh the latency it hides
+#ifndef PMX_ACTOR_GW_EARLY
+#define PMX_ACTOR_GW_EARLY 0                                  // 1: affine parameters loaded before the statistics instead of after
+#endif
 #ifndef PMX_ACTOR_RD
-#define PMX_ACTOR_RD 4                                        // tiles of residual in flight ahead of pass 2
+#define PMX_ACTOR_RD 2                                        // tiles of residual in flight ahead of pass 2
+#endif
+// Development aid (-DPMX_ACTOR_TIMING, never in the shipped build): one wave's s_memtime cycles per phase, summed over its
+// layers and samples, read back with pmx_actor_ticks_read (tools/actor_ticks.py)
+#ifdef PMX_ACTOR_TIMING
+__device__ unsigned long long pmx_actor_ticks[16];
+#define PMX_TICK(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define PMX_TICK_ADD(i, a, b) tick_sum[i] += (b) - (a)
+#else
+#define PMX_TICK(var)
+#define PMX_TICK_ADD(i, a, b)
 #endif
 template <int NT, typename IN_T, bool SAVE>
 __global__ __launch_bounds__(256, 2) void pmx_actor_fwd_kernel(const IN_T *__restrict__ obs, const char *__restrict__ pack,
@@ -219,7 +235,11 @@ __global__ __launch_bounds__(256, 2) void pmx_actor_fwd_kernel(const IN_T *__res
     const float *gnbp = reinterpret_cast<const float *>(pack + PACK_GNB);
     const float inv_n = 1.0f / (float)(8 * G.HW);
 
+#ifdef PMX_ACTOR_TIMING
+    unsigned long long tick_sum[4] = {0, 0, 0, 0};
+#endif
     for (int s = blockIdx.x * 4 + wave; s < B; s += gridDim.x * 4) {
+        PMX_TICK(tk_s);
         wave_lds_fence();
         load_obs<IN_T>(obs + (size_t)s * 8 * G.HW, map, G, lane);
         wave_lds_fence();
@@ -255,6 +275,8 @@ __global__ __launch_bounds__(256, 2) void pmx_actor_fwd_kernel(const IN_T *__res
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bias[m][r] = biasp[l * 32 + 16 * m + 4 * g + r];
+            PMX_TICK(tk0);
+            if (li == 0) PMX_TICK_ADD(3, tk_s, tk0);
             uint2 hp[NT][2];                               // bf16-rounded convolution output (+ bias), packed
             float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
             const char *rbase = map + pq * 64 + g * 16;    // the lane's part of every operand read address
@@ -280,6 +302,8 @@ __global__ __launch_bounds__(256, 2) void pmx_actor_fwd_kernel(const IN_T *__res
                 }
                 __builtin_amdgcn_sched_barrier(0);         // one tile at a time: bounds the registers the scheduler spends on overlap
             }
+            PMX_TICK(tk1);
+            PMX_TICK_ADD(0, tk0, tk1);
             // the map has been read for the last time in this layer: the next layer's weights can start to arrive
             load_frags(A, fws + (size_t)(l + 1 < NLAYER ? l + 1 : l) * FRAG_PER_LAYER, lane);
             // ... and so can everything pass 2 reads from global memory: the affine parameters and the whole residual (the block
@@ -288,10 +312,12 @@ __global__ __launch_bounds__(256, 2) void pmx_actor_fwd_kernel(const IN_T *__res
             // kernel's time at two waves per SIMD).
             constexpr int RD = PMX_ACTOR_RD;
             float gw[2][4], gb[2][4];
+#if PMX_ACTOR_GW_EARLY
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gw[m][r] = gnwp[l * 32 + 16 * m + 4 * g + r], gb[m][r] = gnbp[l * 32 + 16 * m + 4 * g + r];
+#endif
             uint2 rres[NT][2];
 #pragma unroll
             for (int t = 0; t < NT; ++t) rres[t][0] = rres[t][1] = uint2{0u, 0u};
@@ -315,7 +341,15 @@ __global__ __launch_bounds__(256, 2) void pmx_actor_fwd_kernel(const IN_T *__res
                     st[0] = mean[m], st[1] = rstd[m];
                 }
             }
+#if !PMX_ACTOR_GW_EARLY
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gw[m][r] = gnwp[l * 32 + 16 * m + 4 * g + r], gb[m][r] = gnbp[l * 32 + 16 * m + 4 * g + r];
+#endif
             wave_lds_fence();
+            PMX_TICK(tk2);
+            PMX_TICK_ADD(1, tk1, tk2);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const float vm = ((vmk >> t) & 1) ? 1.0f : 0.0f;
@@ -345,8 +379,14 @@ __global__ __launch_bounds__(256, 2) void pmx_actor_fwd_kernel(const IN_T *__res
                 }
             }
             wave_lds_fence();
+            PMX_TICK(tk3);
+            PMX_TICK_ADD(2, tk2, tk3);
         }
     }
+#ifdef PMX_ACTOR_TIMING
+    if (blockIdx.x == 5 && wave == 1 && lane == 0)
+        for (int i = 0; i < 4; ++i) pmx_actor_ticks[(SAVE ? 4 : 0) + i] += tick_sum[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -371,7 +411,7 @@ __global__ __launch_bounds__(256, 1) void pmx_actor_bwd_data_kernel(const char *
     Geom G;
     G.H = H, G.W = W, G.WP = W + 2, G.HW = H * W, G.MP = map_positions(NT, W + 2);
     constexpr int KS = (NT + 1) / 2;
-    constexpr int TG = 4;                                     // tiles per group of global loads (issued together, used behind)
+    constexpr int RD = 4;                                     // tiles of skip-connection data in flight ahead of their use
     char *map = smem + (size_t)wave * (G.MP * 64 + NLAYER * 96 * 4);
     float *acc = reinterpret_cast<float *>(map + (size_t)G.MP * 64);       // [8 layers][bias 32 | gn weight 32 | gn bias 32]
     for (int i = lane; i < G.MP * 4; i += 64) reinterpret_cast<uint4 *>(map)[i] = uint4{0, 0, 0, 0};
@@ -409,55 +449,69 @@ __global__ __launch_bounds__(256, 1) void pmx_actor_bwd_data_kernel(const char *
                 }
             }
         }
+        // What a layer reads from global memory -- its saved pre-activation hp, the block input xg behind its skip connection,
+        // its affine parameters and statistics -- is loaded ONE LAYER AHEAD, into registers the loop carries (at one wave per
+        // SIMD the file has room and nothing else hides a round trip to L2 / HBM).
+        uint2 hp[NT][2], xg[NT][2];
+        float gw[2][4], gb[2][4], mean[2], rstd[2];
+        auto load_layer_inputs = [&](int ln) {
+            const bool res_n = ln >= 3 && (ln & 1);
+            const int lres = ln >= 2 ? ln - 2 : 0;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gw[m][r] = gnwp[ln * 32 + 16 * m + 4 * g + r], gb[m][r] = gnbp[ln * 32 + 16 * m + 4 * g + r];
+                const float *st = stats + (((size_t)ln * B + s) * 4 + 2 * m + (g >> 1)) * 2;
+                mean[m] = st[0], rstd[m] = st[1];                  // (0, 1) for the layers without GroupNorm
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    hp[t][m] = hsave[dump_index((size_t)ln * B + s, NT, t, m, lane)];
+                    if (t < RD) xg[t][m] = uint2{0u, 0u};
+                }
+            if (res_n) {                                           // the first RD tiles; pass 1 asks for the rest as it goes
+#pragma unroll
+                for (int t = 0; t < RD; ++t)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) xg[t][m] = ysave[dump_index((size_t)lres * B + s, NT, t, m, lane)];
+            }
+        };
+        load_layer_inputs(NLAYER - 1);
 #pragma unroll 1
         for (int li = NLAYER - 1; li >= 0; --li) {
             int l = li;
             asm volatile("" : "+s"(l));
             const bool has_gn = l >= 2, has_res = l >= 3 && (l & 1), adds_skip = l >= 2 && !(l & 1);
             const float gn_on = has_gn ? 1.0f : 0.0f;
-            const int lres = l >= 2 ? l - 2 : 0;
             int WPv = G.WP, pq = p + GUARD;
             uint32_t vmk = vmask;
             asm volatile("" : "+s"(WPv));
             asm volatile("" : "+v"(pq), "+v"(vmk));
-            float gw[2][4], gb[2][4], mean[2], rstd[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gw[m][r] = gnwp[l * 32 + 16 * m + 4 * g + r], gb[m][r] = gnbp[l * 32 + 16 * m + 4 * g + r];
-                const float *st = stats + (((size_t)l * B + s) * 4 + 2 * m + (g >> 1)) * 2;
-                mean[m] = st[0], rstd[m] = st[1];                  // (0, 1) for the layers without GroupNorm
-            }
             // ---- pass 1: dz = dY GELU'(z), sums for the GroupNorm backward and for the affine gradients -----------------
-            uint2 hp[NT][2];
             float S1[2] = {0.f, 0.f}, S2[2] = {0.f, 0.f};
             float dgw[2][4], dgb[2][4];
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dgw[m][r] = dgb[m][r] = 0.0f;
+            const uint2 *xsrc = ysave + dump_index((size_t)(l >= 2 ? l - 2 : 0) * B + s, NT, 0, 0, lane);
 #pragma unroll
-            for (int t0 = 0; t0 < NT; t0 += TG) {
-                uint2 xg[TG][2];
+            for (int t = 0; t < NT; ++t) {
+                if (t + RD < NT) {
+                    xg[t + RD][0] = xg[t + RD][1] = uint2{0u, 0u};
+                    if (has_res) {
 #pragma unroll
-                for (int tt = 0; tt < TG; ++tt)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-                        if (t0 + tt < NT) {
-                            hp[t0 + tt][m] = hsave[dump_index((size_t)l * B + s, NT, t0 + tt, m, lane)];
-                            xg[tt][m] = ysave[dump_index((size_t)lres * B + s, NT, t0 + tt, m, lane)];
-                        }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int tt = 0; tt < TG; ++tt)
+                        for (int m = 0; m < 2; ++m) xg[t + RD][m] = xsrc[((t + RD) * 2 + m) * 64];
+                    }
+                }
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
-                        if (t0 + tt < NT) {
-                            const int t = t0 + tt;
-                            const uint2 dy = dv[t][m], h2 = hp[t][m], x2 = xg[tt][m];
+                        {
+                            const uint2 dy = dv[t][m], h2 = hp[t][m], x2 = xg[t][m];
                             const float hv[4] = {lo_f(h2.x), hi_f(h2.x), lo_f(h2.y), hi_f(h2.y)};
-                            const uint32_t xx = has_res ? x2.x : 0u, xy = has_res ? x2.y : 0u;
-                            const float xv[4] = {lo_f(xx), hi_f(xx), lo_f(xy), hi_f(xy)};
+                            const float xv[4] = {lo_f(x2.x), hi_f(x2.x), lo_f(x2.y), hi_f(x2.y)};
                             const float d[4] = {lo_f(dy.x), hi_f(dy.x), lo_f(dy.y), hi_f(dy.y)};
                             float dzf[4], xh[4];
 #pragma unroll
@@ -492,6 +546,7 @@ __global__ __launch_bounds__(256, 1) void pmx_actor_bwd_data_kernel(const char *
 #pragma unroll
             for (int m = 0; m < 2; ++m) S1[m] = group_sum(S1[m]) * inv_n * gn_on, S2[m] = group_sum(S2[m]) * inv_n * gn_on;
             wave_lds_fence();
+            // the flipped weights of the input-gradient convolution: needed after pass 2, asked for now
             // ---- pass 2: dh, into the map (for the input gradient) ---------------------------------------------------------
             float dbias[2][4];
 #pragma unroll
@@ -520,6 +575,22 @@ __global__ __launch_bounds__(256, 1) void pmx_actor_bwd_data_kernel(const char *
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // hp, the affine parameters and the statistics have been used for the last time: the next layer's can start to
+            // arrive, and so can the gradient parked on the skip connection
+            uint2 skip[NT][2];
+#pragma unroll
+            for (int t = 0; t < RD; ++t) skip[t][0] = skip[t][1] = uint2{0u, 0u};
+            if (adds_skip) {
+#pragma unroll
+                for (int t = 0; t < RD; ++t)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) skip[t][m] = skp[(t * 2 + m) * 64];
+            }
+            load_layer_inputs(l > 0 ? l - 1 : 0);
+            const short *bws = bw + (size_t)l * FRAG_PER_LAYER;
+            asm volatile("" : "+s"(bws));
+            bf16x8 A[2][9];
+            load_frags(A, bws, lane);
             // per-channel sums over the sample's positions -> the wave's LDS accumulators (lanes p == 0 own 4 channels each)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -549,24 +620,21 @@ __global__ __launch_bounds__(256, 1) void pmx_actor_bwd_data_kernel(const char *
             }
             // ---- input gradient: the same convolution with flipped, transposed weights; it is the next layer's dY ----------
             if (l > 0) {
-                const short *bws = bw + (size_t)l * FRAG_PER_LAYER;
-                asm volatile("" : "+s"(bws));
-                bf16x8 A[2][9];
-                load_frags(A, bws, lane);
-                uint2 skip[NT][2];
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) skip[t][m] = skp[(t * 2 + m) * 64];
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     f32x4 a[2];
+                    if (t + RD < NT) {
+                        skip[t + RD][0] = skip[t + RD][1] = uint2{0u, 0u};
+                        if (adds_skip) {
+#pragma unroll
+                            for (int m = 0; m < 2; ++m) skip[t + RD][m] = skp[((t + RD) * 2 + m) * 64];
+                        }
+                    }
                     conv_tile(map + pq * 64 + g * 16, A, (WPv + 16 * t) * 64, WPv * 64, a[0], a[1]);
                     const float vm = ((vmk >> t) & 1) ? 1.0f : 0.0f;
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
-                        const uint32_t sx = adds_skip ? skip[t][m].x : 0u, sy = adds_skip ? skip[t][m].y : 0u;
+                        const uint32_t sx = skip[t][m].x, sy = skip[t][m].y;
                         const float v0 = (lo_f(sx) + a[m][0]) * vm, v1 = (hi_f(sx) + a[m][1]) * vm;
                         const float v2 = (lo_f(sy) + a[m][2]) * vm, v3 = (hi_f(sy) + a[m][3]) * vm;
                         uint2 nx = {pack2(v0, v1), pack2(v2, v3)};
@@ -957,3 +1025,15 @@ extern "C" int pmx_actor_backward(const void *obs_dev, int32_t obs_dtype, const 
     PMX_BWD(11)
 #undef PMX_BWD
 }
+
+#ifdef PMX_ACTOR_TIMING
+extern "C" int pmx_actor_ticks_read(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pmx_actor_ticks), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pmx_actor_ticks), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
