@@ -257,6 +257,13 @@ int pmx_attn8_forward(const void *qkv_dev, void *out_dev, float *lse_dev, int32_
 /* Its backward pass: dqkv_dev [S][B][96] bfloat16 from the saved qkv, out, lse and the incoming dout [S][B][32].  S <= 640. */
 int pmx_attn8_backward(const void *qkv_dev, const void *out_dev, const void *dout_dev, const float *lse_dev, void *dqkv_dev,
                        int32_t S, int32_t B, void *stream);
+/* The same two kernels on batch-major tensors when batch_major != 0: qkv [B][S][96], out / dout [B][S][32], dqkv [B][S][96]
+ * (lse stays [B][4][S]).  That is the memory order of a channels-last convolution output [B][H][W][32] read as tokens, so the
+ * critic (pacman_mappo_resnet.py:160-170: projector -> flatten(2).permute(2, 0, 1) -> encoder) needs no transposing copy
+ * between its convolution and its encoder layers, and a sample's rows are contiguous for the kernels. */
+int pmx_attn8_forward_layout(const void *qkv_dev, void *out_dev, float *lse_dev, int32_t S, int32_t B, int32_t batch_major, void *stream);
+int pmx_attn8_backward_layout(const void *qkv_dev, const void *out_dev, const void *dout_dev, const float *lse_dev, void *dqkv_dev,
+                              int32_t S, int32_t B, int32_t batch_major, void *stream);
 
 /* ---- The actor's convolutional tower as one forward and one backward kernel ------------------------------------------
  * MAPPOAgent.actor_backbone (pacman_mappo_resnet.py:104-113 with ResidualBlock :49-67):

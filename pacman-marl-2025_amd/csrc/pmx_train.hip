@@ -610,7 +610,7 @@ __device__ __forceinline__ short pmx_f2bf(float f)
 }
 
 __global__ __launch_bounds__(512) void pmx_attn8_fwd_kernel(const __hip_bfloat16 *__restrict__ qkv, __hip_bfloat16 *__restrict__ out,
-                                                            float *__restrict__ lse, int S, int B, float scale)
+                                                            float *__restrict__ lse, int S, int B, float scale, int bm)
 {
     constexpr int D = 8, HEADS = 4, E = 32;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -621,8 +621,11 @@ __global__ __launch_bounds__(512) void pmx_attn8_fwd_kernel(const __hip_bfloat16
     short *Ks = reinterpret_cast<short *>(smem) + (size_t)h * 2 * S_pad * D;
     short *Vt = Ks + (size_t)S_pad * D;
     const short *base = reinterpret_cast<const short *>(qkv);
-    const size_t row_stride = (size_t)B * 3 * E;                     // elements between consecutive sequence positions
-    const size_t head_off = (size_t)b * 3 * E + (size_t)h * D;
+    // elements between consecutive sequence positions: sequence-major [S][B][.] (nn.MultiheadAttention's batch_first=False) or
+    // batch-major [B][S][.] (bm: a sample's rows are one contiguous 192 S bytes)
+    const size_t row_stride = bm ? (size_t)3 * E : (size_t)B * 3 * E;
+    const size_t head_off = (size_t)b * 3 * E * (bm ? S : 1) + (size_t)h * D;
+    const size_t out_row = bm ? (size_t)E : (size_t)B * E, out_off = (size_t)b * E * (bm ? S : 1) + (size_t)h * D;
     for (int s = lane + 64 * role; s < S_pad; s += 128) {
         uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
         if (s < S) {
@@ -707,7 +710,7 @@ __global__ __launch_bounds__(512) void pmx_attn8_fwd_kernel(const __hip_bfloat16
                 short w4[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) w4[r] = pmx_f2bf(o[r] * inv);
-                *reinterpret_cast<uint2 *>(reinterpret_cast<short *>(out) + ((size_t)q_row * B + b) * E + h * D + g * 4) =
+                *reinterpret_cast<uint2 *>(reinterpret_cast<short *>(out) + (size_t)q_row * out_row + out_off + g * 4) =
                     *reinterpret_cast<const uint2 *>(w4);
             }
             if (g == 0 && lse) lse[((size_t)b * HEADS + h) * S + q_row] = (m + __log2f(l)) * 0.69314718055994531f;   // back to the natural log
@@ -716,8 +719,12 @@ __global__ __launch_bounds__(512) void pmx_attn8_fwd_kernel(const __hip_bfloat16
 }
 
 // qkv_dev [S][B][96] bf16 (the packed in-projection of nn.MultiheadAttention with embed 32, 4 heads), out_dev [S][B][32]
-// bf16, lse_dev [B][4][S] float32 (log-sum-exp of the scaled scores per query; may be NULL).
+// bf16, lse_dev [B][4][S] float32 (log-sum-exp of the scaled scores per query; may be NULL).  batch_major: [B][S][.] instead.
 extern "C" int pmx_attn8_forward(const void *qkv_dev, void *out_dev, float *lse_dev, int32_t S, int32_t B, void *stream)
+{
+    return pmx_attn8_forward_layout(qkv_dev, out_dev, lse_dev, S, B, 0, stream);
+}
+extern "C" int pmx_attn8_forward_layout(const void *qkv_dev, void *out_dev, float *lse_dev, int32_t S, int32_t B, int32_t batch_major, void *stream)
 {
     if (!qkv_dev || !out_dev || S < 1 || S > 1024 || B < 0) return PMX_ERR_INVALID;
     if (B == 0) return PMX_OK;
@@ -734,7 +741,7 @@ extern "C" int pmx_attn8_forward(const void *qkv_dev, void *out_dev, float *lse_
         attr_set = true;
     }
     hipLaunchKernelGGL(pmx_attn8_fwd_kernel, dim3(B), dim3(512), lds, st, (const __hip_bfloat16 *)qkv_dev, (__hip_bfloat16 *)out_dev, lse_dev, S, B,
-                       0.35355339059327379f /* 1/sqrt(8) */);
+                       0.35355339059327379f /* 1/sqrt(8) */, batch_major ? 1 : 0);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
 
@@ -756,7 +763,7 @@ extern "C" int pmx_attn8_forward(const void *qkv_dev, void *out_dev, float *lse_
 template <int NPF>
 __global__ __launch_bounds__(512) void pmx_attn8_bwd_kernel(const __hip_bfloat16 *__restrict__ qkv, const __hip_bfloat16 *__restrict__ outp,
                                                             const __hip_bfloat16 *__restrict__ dout, const float *__restrict__ lse,
-                                                            __hip_bfloat16 *__restrict__ dqkv, int S, int B, float scale)
+                                                            __hip_bfloat16 *__restrict__ dqkv, int S, int B, float scale, int bm)
 {
     constexpr int D = 8, HEADS = 4, E = 32;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -773,8 +780,8 @@ __global__ __launch_bounds__(512) void pmx_attn8_bwd_kernel(const __hip_bfloat16
     const short *base = reinterpret_cast<const short *>(qkv);
     const short *obase = reinterpret_cast<const short *>(outp);
     const short *dobase = reinterpret_cast<const short *>(dout);
-    const size_t row_stride = (size_t)B * 3 * E, orow = (size_t)B * E;
-    const size_t head_off = (size_t)b * 3 * E + (size_t)h * D, ohead = (size_t)b * E + (size_t)h * D;
+    const size_t row_stride = bm ? (size_t)3 * E : (size_t)B * 3 * E, orow = bm ? (size_t)E : (size_t)B * E;      // as in the forward kernel
+    const size_t head_off = (size_t)b * 3 * E * (bm ? S : 1) + (size_t)h * D, ohead = (size_t)b * E * (bm ? S : 1) + (size_t)h * D;
 
     for (int s = lane + 64 * role; s < S_pad; s += 128) {
         uint4 qv = make_uint4(0, 0, 0, 0), kv = qv, dov = qv, ov = qv;
@@ -989,6 +996,11 @@ __global__ __launch_bounds__(512) void pmx_attn8_bwd_kernel(const __hip_bfloat16
 extern "C" int pmx_attn8_backward(const void *qkv_dev, const void *out_dev, const void *dout_dev, const float *lse_dev, void *dqkv_dev,
                                   int32_t S, int32_t B, void *stream)
 {
+    return pmx_attn8_backward_layout(qkv_dev, out_dev, dout_dev, lse_dev, dqkv_dev, S, B, 0, stream);
+}
+extern "C" int pmx_attn8_backward_layout(const void *qkv_dev, const void *out_dev, const void *dout_dev, const float *lse_dev, void *dqkv_dev,
+                                         int32_t S, int32_t B, int32_t batch_major, void *stream)
+{
     if (!qkv_dev || !out_dev || !dout_dev || !lse_dev || !dqkv_dev || S < 1 || S > 640 || B < 0) return PMX_ERR_INVALID;
     if (B == 0) return PMX_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1006,10 +1018,10 @@ extern "C" int pmx_attn8_backward(const void *qkv_dev, const void *out_dev, cons
     static const bool generic_only = getenv("PMX_ATTN_BWD_GENERIC") != nullptr;      // A/B switch, read once
     if (S_pad == 160 && !generic_only)       // tinyCapture and smallCapture (154 cells): the row operands of a wave fit in 80 registers
         hipLaunchKernelGGL(pmx_attn8_bwd_kernel<5>, dim3(B), dim3(512), lds, st, (const __hip_bfloat16 *)qkv_dev, (const __hip_bfloat16 *)out_dev,
-                           (const __hip_bfloat16 *)dout_dev, lse_dev, (__hip_bfloat16 *)dqkv_dev, S, B, 0.35355339059327379f);
+                           (const __hip_bfloat16 *)dout_dev, lse_dev, (__hip_bfloat16 *)dqkv_dev, S, B, 0.35355339059327379f, batch_major ? 1 : 0);
     else
         hipLaunchKernelGGL(pmx_attn8_bwd_kernel<0>, dim3(B), dim3(512), lds, st, (const __hip_bfloat16 *)qkv_dev, (const __hip_bfloat16 *)out_dev,
-                           (const __hip_bfloat16 *)dout_dev, lse_dev, (__hip_bfloat16 *)dqkv_dev, S, B, 0.35355339059327379f);
+                           (const __hip_bfloat16 *)dout_dev, lse_dev, (__hip_bfloat16 *)dqkv_dev, S, B, 0.35355339059327379f, batch_major ? 1 : 0);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
 

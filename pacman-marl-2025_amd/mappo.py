@@ -219,28 +219,30 @@ def ffn_layer_norm(x, lin1, lin2, ln):
     return add_layer_norm_small(x, f, ln)
 
 
-def attention8_forward(qkv, want_lse=False):
-    """softmax(q k^T / sqrt(8)) v for 4 heads of 8 on the matrix cores (pmx_attn8_forward): qkv [S, B, 96] bfloat16 ->
-    [S, B, 32] bfloat16 (+ log-sum-exp [B, 4, S] float32)."""
+def attention8_forward(qkv, want_lse=False, batch_major=False):
+    """softmax(q k^T / sqrt(8)) v for 4 heads of 8 on the matrix cores (pmx_attn8_forward_layout): qkv [S, B, 96] bfloat16 ->
+    [S, B, 32] bfloat16 (+ log-sum-exp [B, 4, S] float32); with batch_major qkv is [B, S, 96] and the result [B, S, 32]."""
     import ctypes as C
     from . import _lib
     lib = _lib.load()
-    S, B, _ = qkv.shape
+    (B, S, _) = qkv.shape if batch_major else (qkv.shape[1], qkv.shape[0], 0)
     qkv = qkv.contiguous()
-    out = torch.empty(S, B, 32, dtype=torch.bfloat16, device=qkv.device)
+    out = torch.empty(qkv.shape[0], qkv.shape[1], 32, dtype=torch.bfloat16, device=qkv.device)
     lse = torch.empty(B, 4, S, dtype=torch.float32, device=qkv.device) if want_lse else None
     st = C.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)
-    _lib.check(lib.pmx_attn8_forward(qkv.data_ptr(), out.data_ptr(), lse.data_ptr() if want_lse else None, S, B, st), "pmx_attn8_forward")
+    _lib.check(lib.pmx_attn8_forward_layout(qkv.data_ptr(), out.data_ptr(), lse.data_ptr() if want_lse else None, S, B,
+                                            1 if batch_major else 0, st), "pmx_attn8_forward")
     return (out, lse) if want_lse else out
 
 
 class _Attention8(torch.autograd.Function):
-    """Differentiable wrapper of the MFMA attention kernels (pmx_attn8_forward / pmx_attn8_backward)."""
+    """Differentiable wrapper of the MFMA attention kernels (pmx_attn8_forward_layout / pmx_attn8_backward_layout)."""
 
     @staticmethod
-    def forward(ctx, qkv):
-        out, lse = attention8_forward(qkv, want_lse=True)
+    def forward(ctx, qkv, batch_major):
+        out, lse = attention8_forward(qkv, want_lse=True, batch_major=batch_major)
         ctx.save_for_backward(qkv.contiguous(), out, lse)
+        ctx.batch_major = batch_major
         return out
 
     @staticmethod
@@ -249,17 +251,17 @@ class _Attention8(torch.autograd.Function):
         from . import _lib
         lib = _lib.load()
         qkv, out, lse = ctx.saved_tensors
-        S, B, _ = qkv.shape
+        B, S = lse.shape[0], lse.shape[2]
         gout = gout.contiguous().to(torch.bfloat16)
         dqkv = torch.empty_like(qkv)
         st = C.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)
-        _lib.check(lib.pmx_attn8_backward(qkv.data_ptr(), out.data_ptr(), gout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), S, B, st),
-                   "pmx_attn8_backward")
-        return dqkv
+        _lib.check(lib.pmx_attn8_backward_layout(qkv.data_ptr(), out.data_ptr(), gout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), S, B,
+                                                 1 if ctx.batch_major else 0, st), "pmx_attn8_backward")
+        return dqkv, None
 
 
-def attention8(qkv):
-    return _Attention8.apply(qkv)
+def attention8(qkv, batch_major=False):
+    return _Attention8.apply(qkv, batch_major)
 
 
 def column_sums(t):
@@ -326,7 +328,7 @@ class CriticEncoderLayer(nn.TransformerEncoderLayer):
         if x.is_cuda and torch.is_autocast_enabled() and x.dtype != torch.bfloat16:
             x = x.to(torch.bfloat16)
         qkv = in_proj96(x, mha) if (E == 32 and h == 4) else token_linear(x, mha.in_proj_weight, mha.in_proj_bias)
-        if qkv.is_cuda and qkv.dtype == torch.bfloat16 and E == 32 and h == 4 and S <= (640 if torch.is_grad_enabled() else 1024):
+        if self.fused_ok(qkv, S):
             a = attention8(qkv) if torch.is_grad_enabled() else attention8_forward(qkv)   # hand-written MFMA attention
             x = out_proj_add_layer_norm(x, a, mha.out_proj, self.norm1)
             return ffn_layer_norm(x, self.linear1, self.linear2, self.norm2)
@@ -338,6 +340,21 @@ class CriticEncoderLayer(nn.TransformerEncoderLayer):
         x = add_layer_norm_small(x, a, self.norm1)
         f = token_linear(F.relu(token_linear(x, self.linear1.weight, self.linear1.bias)), self.linear2.weight, self.linear2.bias)
         return add_layer_norm_small(x, f, self.norm2)
+
+    def fused_ok(self, t, S):
+        """True when the hand-written kernels take this layer's tensors: bfloat16 on the GPU, embed 32, 4 heads, S in range."""
+        mha = self.self_attn
+        return (t.is_cuda and t.dtype == torch.bfloat16 and mha.embed_dim == 32 and mha.num_heads == 4
+                and S <= (640 if torch.is_grad_enabled() else 1024))
+
+    def forward_batch_major(self, x):
+        """The same layer on x [B, S, 32] bfloat16 (tokens of a sample contiguous: the memory order of a channels-last
+        convolution output), hand-written kernels only; the caller has checked fused_ok."""
+        mha = self.self_attn
+        qkv = in_proj96(x, mha)
+        a = attention8(qkv, True) if torch.is_grad_enabled() else attention8_forward(qkv, batch_major=True)
+        x = out_proj_add_layer_norm(x, a, mha.out_proj, self.norm1)
+        return ffn_layer_norm(x, self.linear1, self.linear2, self.norm2)
 
 
 class _GN8Gelu(torch.autograd.Function):
@@ -440,10 +457,13 @@ class PositionalEncoding2D(nn.Module):
         self.register_buffer("y_enc", table(max_h))
         self.register_buffer("x_enc", table(max_w))
 
+    def table(self, H, W):
+        """[H, W, d_model]"""
+        return torch.cat([self.y_enc[:H, None, :].expand(H, W, -1), self.x_enc[None, :W, :].expand(H, W, -1)], dim=2)
+
     def forward(self, x):
         _, _, H, W = x.shape
-        pos = torch.cat([self.y_enc[:H, None, :].expand(H, W, -1), self.x_enc[None, :W, :].expand(H, W, -1)], dim=2)
-        return x + pos.permute(2, 0, 1).unsqueeze(0).to(x.dtype)
+        return x + self.table(H, W).permute(2, 0, 1).unsqueeze(0).to(x.dtype)
 
 
 class MAPPOAgent(nn.Module):
@@ -479,6 +499,7 @@ class MAPPOAgent(nn.Module):
 
     fused_ffn = True        # use the fused feed-forward + LayerNorm kernels of the critic's encoder layers (bf16 on the GPU)
     fused_tower = True      # use the fused actor-tower kernels where they apply (bf16 on the GPU, supported board size)
+    batch_major_critic = True   # run the critic channels-last / batch-major under bf16 autocast on the GPU (no transposing copies)
     tower_pack = None       # packed tower parameters for inference, set by a caller that knows the weights are frozen
                             # (VecMAPPOTrainer.rollout); None = pack on every call
 
@@ -519,6 +540,23 @@ class MAPPOAgent(nn.Module):
         """merged_obs [B,8,H,W] -> [B] (pacman_mappo_resnet.py:160-170)"""
         if merged_obs.dtype == torch.uint8:
             merged_obs = merged_obs.to(torch.bfloat16 if (merged_obs.is_cuda and torch.is_autocast_enabled()) else torch.float32)
+        layers = self.critic_transformer.layers
+        if (self.batch_major_critic and merged_obs.is_cuda and torch.is_autocast_enabled() and self.fused_ffn
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16 and layers[0].fused_ok(merged_obs.new_empty(0, dtype=torch.bfloat16),
+                                                                                              merged_obs.shape[2] * merged_obs.shape[3])):
+            # channels-last end to end: the projector's output [B, H, W, d] IS the token tensor [B, S, d] (no transposing copy
+            # on the way in, none for its gradient on the way back) and the encoder layers run batch-major
+            B, _, H, W = merged_obs.shape
+            y = self.critic_projector(merged_obs.contiguous(memory_format=torch.channels_last))
+            x = y.permute(0, 2, 3, 1)
+            if not x.is_contiguous():
+                x = x.contiguous()
+            x = (x + self.pos_encoder.table(H, W).to(x.dtype)).reshape(B, H * W, self.d_model)
+            for layer in layers:
+                x = layer.forward_batch_major(x)
+            if self.critic_transformer.norm is not None:
+                x = self.critic_transformer.norm(x)
+            return self.critic_head(x.mean(dim=1)).squeeze(-1)
         x = self.pos_encoder(self.critic_projector(merged_obs))
         x = x.flatten(2).permute(2, 0, 1)                                # [H*W, B, d]
         x = self.critic_transformer(x).mean(dim=0)

@@ -495,3 +495,50 @@ def test_fused_in_projection_and_out_projection_layernorm_match_torch(tokens):
     assert (y.detach().cpu().double() - yc.detach()).abs().max().item() <= 2 * 2 ** -8 * max(1.0, yc.abs().max().item())
     for g_, w_ in zip(got, want):
         assert ((g_.detach().cpu().double() - w_).norm() / (w_.norm() + 1e-12)).item() < 2e-2, tuple(w_.shape)
+
+
+@pytest.mark.parametrize("S,B", [(154, 19), (140, 5), (400, 3)])
+def test_batch_major_attention_equals_sequence_major(S, B):
+    """pmx_attn8_forward_layout / _backward_layout with batch_major on [B, S, .] tensors give bit for bit what the sequence-major
+    kernels give on the transposed tensors: the layout only changes addresses."""
+    from pmx import mappo
+    torch.manual_seed(S + 7)
+    qkv = (torch.randn(S, B, 96, device="cuda") * 1.4).to(torch.bfloat16)
+    g = torch.randn(S, B, 32, device="cuda").to(torch.bfloat16)
+    a = qkv.clone().requires_grad_(True)
+    out_a = mappo.attention8(a)
+    out_a.backward(g)
+    b = qkv.transpose(0, 1).contiguous().requires_grad_(True)
+    out_b = mappo.attention8(b, True)
+    out_b.backward(g.transpose(0, 1).contiguous())
+    assert torch.equal(out_a.transpose(0, 1), out_b)
+    assert torch.equal(a.grad.transpose(0, 1), b.grad)
+    with torch.no_grad():
+        assert torch.equal(mappo.attention8_forward(b.detach(), batch_major=True), out_b)
+
+
+def test_batch_major_critic_matches_sequence_major_critic():
+    """MAPPOAgent.value under bf16 autocast: the channels-last / batch-major path against the [S, B, E] path of the same
+    weights -- same kernels on permuted tokens, so values agree to bf16 rounding of the convolution (MIOpen picks another
+    algorithm for NHWC) and the gradients to the same."""
+    from pmx import mappo
+    torch.manual_seed(3)
+    H, W = 11, 14
+    m = mappo.MAPPOAgent((8, H, W)).cuda()
+    merged = (torch.rand(96, 8, H, W, device="cuda") < 0.2).to(torch.uint8)
+    res = {}
+    for bm in (False, True):
+        m.batch_major_critic = bm
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            v = m.value(merged).float()
+        (v * torch.linspace(-1, 1, v.numel(), device="cuda")).sum().backward()
+        res[bm] = (v.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    m.batch_major_critic = True
+    v0, g0 = res[False]
+    v1, g1 = res[True]
+    assert float((v0 - v1).abs().max()) <= 2e-2 * (float(v0.abs().max()) + 1e-3), float((v0 - v1).abs().max())
+    assert g0.keys() == g1.keys() and any(n.startswith("critic_projector") for n in g0)
+    for n in g0:
+        rel = float((g0[n] - g1[n]).norm() / (g0[n].norm() + 1e-9))
+        assert rel <= 5e-2, (n, rel)
