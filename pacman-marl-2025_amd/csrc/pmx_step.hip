@@ -34,6 +34,7 @@ struct Env {
 struct Acc {
     double red_r, blue_r;
     int red_sc, blue_sc, sc_total;
+    int n_red, n_blue;     // pellets on the red / blue half (capture.py:332-342), kept up to date by the hot kernel only (HB > 0)
 };
 
 struct Ctx {
@@ -52,6 +53,8 @@ struct Ctx {
     const uint8_t *dist;  // this env's layout's maze-distance matrix (or NULL)
     const int16_t *cidx;  // its cell -> matrix row map
     int n_cells;
+    uint32_t *rows0;      // LDS: row 0 of the whole block's food rows ([row][lane]; fd = rows0 + lane)
+    uint32_t *stg;        // LDS: [16][PMX_RULE_BLOCK] staging words of the wide snapshot / state stores
 };
 
 __device__ __forceinline__ uint32_t pack_a(const Env &e, int i)
@@ -357,6 +360,7 @@ __device__ __forceinline__ void tick_substep(Env &e, Acc &a, const Ctx &c, int a
     }
     if (c.legal_reward && req_legal) r += 0.01;                           // :254-257
     if (RED) { a.red_r = r; a.red_sc += sc; } else { a.blue_r = r; a.blue_sc -= sc; }
+    a.n_red += d_red; a.n_blue += d_blue;
     a.sc_total += sc;                                                     // :153-162
     e.self_after[I] = e.xy[I] | ((uint32_t)e.carry[I] << 16);
 }
@@ -398,6 +402,15 @@ __device__ __forceinline__ void load_env_commit(Env &e, const Ctx &c, const RawE
     for (int y = 0; y < HB; ++y)
         if (y < c.H) c.fd[y * PMX_RULE_BLOCK] = rows[y];
 }
+// capture.py:332-342 halfGrid sums of the state as loaded (the rows are still in registers: no LDS round trip)
+template <int HB>
+__device__ __forceinline__ void count_food(Acc &a, const Ctx &c, const uint32_t (&rows)[HB])
+{
+    int nr = 0, nb = 0;
+#pragma unroll
+    for (int y = 0; y < HB; ++y) { nr += __popc(rows[y] & c.lo_mask); nb += __popc(rows[y] & c.hi_mask); }
+    a.n_red = nr; a.n_blue = nb;
+}
 
 __device__ __forceinline__ void load_env(Env &e, const Ctx &c, const uint32_t *st, int N, int env)
 {
@@ -433,6 +446,60 @@ __device__ __forceinline__ void store_snapshot(const Env &e, const Ctx &c, uint3
     }
     st[(size_t)PMX_W_CAPS(c.H, 0) * N + env] = e.capw[0];
     st[(size_t)PMX_W_CAPS(c.H, 1) * N + env] = e.capw[1];
+}
+// The same words with 16-byte stores: a dword store per word and lane is 22 (snapshot) or 25 (state) store instructions of
+// 256 bytes each, and on a kernel that runs ONE wave per CU their issue time is on the critical path (s_memtime: a sub-step
+// with its snapshot took 2 250-2 700 ticks, one without 1 200).  The SoA rows of 64 consecutive envs are 256 contiguous
+// bytes, and the food rows already sit in LDS as [row][lane]: lane L of instruction k reads row 4k + (L >> 4), envs
+// 4 (L & 15) .. + 3 with one ds_read_b128 and stores them with one global_store_dwordx4 -- 3 + 3 instructions per snapshot
+// instead of 22.  The non-row words go through an LDS staging block in the same shape.  Needs all 64 lanes live
+// (N % 64 == 0), which the caller checks; LDS operations of one wave execute in order, so later row updates cannot overtake.
+// rows 4k + sub (k = K0 .. K1 - 1) of an LDS block [row][lane] -> SoA words (word0 + row) of 64 envs, 16 bytes per lane
+template <int K0, int K1>
+__device__ __forceinline__ void wide_group(const uint32_t *lds_rows, int n_rows, int word0, int sub, int q4, uint32_t *dst, int N)
+{
+    if constexpr (K0 < K1) {
+        const int r = 4 * K0 + sub;
+        const uint4 v = *reinterpret_cast<const uint4 *>(lds_rows + (r < n_rows ? r : 0) * PMX_RULE_BLOCK + q4);
+        wide_group<K0 + 1, K1>(lds_rows, n_rows, word0, sub, q4, dst, N);       // the later reads are issued before this store
+        if (r < n_rows) *reinterpret_cast<uint4 *>(dst + (size_t)(word0 + r) * N) = v;
+    }
+}
+template <int HB, int NW>
+__device__ __forceinline__ void store_words_wide(const Ctx &c, const uint32_t (&w)[NW], uint32_t *st, int N)
+{
+    const int lane = threadIdx.x, sub = lane >> 4, q4 = 4 * (lane & 15);
+    uint32_t *dst = st + (size_t)blockIdx.x * PMX_RULE_BLOCK + q4;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) c.stg[i * PMX_RULE_BLOCK + lane] = w[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // (reads unconditional, with the row clamped, and no register ARRAY of them: an array the compiler cannot fully scalarise
+    // goes to scratch memory, and a scratch reload waits for vmcnt(0), i.e. for every store in flight)
+    constexpr int KR = HB / 4, KW = (NW + 3) / 4;
+    wide_group<0, KR>(c.rows0, c.H, 0, sub, q4, dst, N);
+    wide_group<0, KW>(c.stg, NW, c.H, sub, q4, dst, N);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // the staging block is rewritten by the next call
+    __builtin_amdgcn_wave_barrier();
+}
+template <int HB>
+__device__ __forceinline__ void store_snapshot_wide(const Env &e, const Ctx &c, uint32_t *st, int N)
+{
+    uint32_t w[10];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { w[i] = pack_a(e, i); w[4 + i] = pack_b(e, i); }
+    w[8] = e.capw[0]; w[9] = e.capw[1];
+    store_words_wide<HB, 10>(c, w, st, N);
+}
+template <int HB>
+__device__ __forceinline__ void store_env_wide(const Env &e, const Ctx &c, uint32_t *st, int N)
+{
+    uint32_t w[13];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { w[i] = pack_a(e, i); w[4 + i] = pack_b(e, i); }
+    w[8] = e.capw[0]; w[9] = e.capw[1];
+    w[10] = (uint32_t)e.score; w[11] = (uint32_t)e.steps; w[12] = e.ticks;
+    store_words_wide<HB, 13>(c, w, st, N);
 }
 template <int HB = 0>
 __device__ __forceinline__ void store_env(const Env &e, const Ctx &c, uint32_t *st, int N, int env)
@@ -483,12 +550,7 @@ __device__ __forceinline__ void tick_finish(Env &e, Acc &a, const Ctx &c_in, con
     double red_r = a.red_r + (double)(a.red_sc > 0 ? a.red_sc : 0);
     int n_red = 0, n_blue = 0;                                            // capture.py:332-342 halfGrid sums
     if constexpr (HB > 0) {
-#pragma unroll
-        for (int y = 0; y < HB; ++y) {
-            const uint32_t row = y < c.H ? c.fd[y * PMX_RULE_BLOCK] : 0u;
-            n_red += __popc(row & c.lo_mask);
-            n_blue += __popc(row & c.hi_mask);
-        }
+        n_red = a.n_red; n_blue = a.n_blue;      // counted when the state was loaded, updated by every eaten / dumped pellet
     } else {
         for (int y = 0; y < c.H; ++y) {
             uint32_t row = c.fd[y * PMX_RULE_BLOCK];
@@ -540,6 +602,8 @@ __device__ __forceinline__ Ctx make_ctx(const PmxTickParams &p, uint32_t *lds)
     c.wl = multi ? lds + 32 + PMX_MAX_H_LDS * PMX_RULE_BLOCK + threadIdx.x : lds;
     c.wls = multi ? PMX_RULE_BLOCK : 1;
     c.fd = lds + 32 + threadIdx.x;
+    c.rows0 = lds + 32;
+    c.stg = lds + 32 + (multi ? (3 * PMX_MAX_H_LDS + 32) : 3 * c.H) * PMX_RULE_BLOCK;
     c.fd2 = multi ? lds + 32 + 2 * PMX_MAX_H_LDS * PMX_RULE_BLOCK + threadIdx.x : lds + 32 + c.H * PMX_RULE_BLOCK + threadIdx.x;
     c.fd3 = multi ? lds + 32 + 3 * PMX_MAX_H_LDS * PMX_RULE_BLOCK + threadIdx.x : lds + 32 + 2 * c.H * PMX_RULE_BLOCK + threadIdx.x;
     c.dist = p.dist ? p.dist + c.L->dist_off : nullptr;
@@ -564,11 +628,23 @@ __device__ __forceinline__ Ctx make_ctx(const PmxTickParams &p, uint32_t *lds)
 
 }  // namespace
 
+// Development aid (-DPMX_RULE_TIMING, never in the shipped build): s_memtime stamps of the phases of the wave of block 0, summed
+// over launches in pmx_rule_ticks[] (start->ctx, ->state unpacked, four sub-steps with their snapshot stores, finish, state store)
+#ifdef PMX_RULE_TIMING
+__device__ unsigned long long pmx_rule_ticks[16];
+#define PMX_RTICK(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0 && threadIdx.x == 0) pmx_rule_ticks[i] += now_ - last_; last_ = now_; } while (0)
+#else
+#define PMX_RTICK(i) do { } while (0)
+#endif
+
 // dynamic LDS: 32 wall rows + 3 x H rows x PMX_RULE_BLOCK lanes (food, bots' scratch copy, dump_food's blocked-cell rows)
 template <bool BOTS, int HB>
 __global__ __launch_bounds__(PMX_RULE_BLOCK) void pmx_rule_kernel(PmxTickParams p)
 {
     extern __shared__ uint32_t lds[];
+#ifdef PMX_RULE_TIMING
+    unsigned long long last_ = __builtin_amdgcn_s_memtime();
+#endif
     const int env = blockIdx.x * PMX_RULE_BLOCK + threadIdx.x;
     const bool live = env < p.N;
     RawEnv raw;
@@ -579,20 +655,33 @@ __global__ __launch_bounds__(PMX_RULE_BLOCK) void pmx_rule_kernel(PmxTickParams 
         av = reinterpret_cast<const uint32_t *>(p.actions)[env];   // 4 int8 actions
     }
     Ctx c = make_ctx(p, lds);
+    PMX_RTICK(0);
     if (!live) return;
     Env e;
     load_env_commit<HB>(e, c, raw, rows);
-    Acc a = { 0.0, 0.0, 0, 0, 0 };
+    PMX_RTICK(1);
+    Acc a = { 0.0, 0.0, 0, 0, 0, 0, 0 };
+    count_food<HB>(a, c, rows);
     const size_t snap_sz = (size_t)PMX_SNAP_WORDS(c.H) * p.N;
+    const bool wide = (p.N & (PMX_RULE_BLOCK - 1)) == 0;          // every wave is full: the 16-byte store path (store_words_wide)
     tick_substep<0, BOTS>(e, a, c, (int)(int8_t)(av & 0xFF));
-    store_snapshot<HB>(e, c, p.snap, p.N, env);
+    if (wide) store_snapshot_wide<HB>(e, c, p.snap, p.N); else store_snapshot<HB>(e, c, p.snap, p.N, env);
+    PMX_RTICK(2);
     tick_substep<1, BOTS>(e, a, c, (int)(int8_t)((av >> 8) & 0xFF));
-    store_snapshot<HB>(e, c, p.snap + snap_sz, p.N, env);
+    if (wide) store_snapshot_wide<HB>(e, c, p.snap + snap_sz, p.N); else store_snapshot<HB>(e, c, p.snap + snap_sz, p.N, env);
+    PMX_RTICK(3);
     tick_substep<2, BOTS>(e, a, c, (int)(int8_t)((av >> 16) & 0xFF));
-    store_snapshot<HB>(e, c, p.snap + 2 * snap_sz, p.N, env);
+    if (wide) store_snapshot_wide<HB>(e, c, p.snap + 2 * snap_sz, p.N); else store_snapshot<HB>(e, c, p.snap + 2 * snap_sz, p.N, env);
+    PMX_RTICK(4);
     tick_substep<3, BOTS>(e, a, c, (int)(int8_t)((av >> 24) & 0xFF));
+    PMX_RTICK(5);
     tick_finish<HB>(e, a, c, p, env, true);
-    store_env<HB>(e, c, p.state, p.N, env);
+    PMX_RTICK(6);
+    if (wide) store_env_wide<HB>(e, c, p.state, p.N); else store_env<HB>(e, c, p.state, p.N, env);
+    PMX_RTICK(7);
+#ifdef PMX_RULE_TIMING
+    if (blockIdx.x == 0 && threadIdx.x == 0) pmx_rule_ticks[15] += 1;
+#endif
 }
 
 // pmx_step_agent: one sub-step; the accumulators of the open tick travel through the state words.
@@ -604,7 +693,7 @@ __device__ __forceinline__ void rule_agent_body(const PmxTickParams &p, uint32_t
     if (env >= p.N) return;
     Env e;
     load_env(e, c, p.state, p.N, env);
-    Acc a = { 0.0, 0.0, 0, 0, 0 };
+    Acc a = { 0.0, 0.0, 0, 0, 0, 0, 0 };
     uint32_t *acc = p.state + (size_t)PMX_W_ACC(c.H) * p.N + env;
     if (I > 0) {
         a.red_r = __hiloint2double((int)acc[(size_t)1 * p.N], (int)acc[0]);
@@ -1129,7 +1218,7 @@ extern "C" hipError_t pmx_launch_emit_team(const PmxEmitParams *p, int dtype, hi
 extern "C" hipError_t pmx_launch_rule(const PmxTickParams *p, int H, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1)
 {
     const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
-    const size_t lds = (p->layout_idx ? 32 + (size_t)(3 * PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)3 * H * PMX_RULE_BLOCK) * sizeof(uint32_t);
+    const size_t lds = (p->layout_idx ? 32 + (size_t)(3 * PMX_MAX_H_LDS + 32 + 16) * PMX_RULE_BLOCK : 32 + (size_t)(3 * H + 16) * PMX_RULE_BLOCK) * sizeof(uint32_t);
     // row loops unrolled for the board-height bucket (see load_env_issue)
     const int hb = H <= 12 ? 12 : (H <= 16 ? 16 : (H <= 20 ? 20 : 32));
 #define PMX_RULE_LAUNCH(B, HBV)                                                                                         \
@@ -1151,7 +1240,7 @@ extern "C" hipError_t pmx_launch_rule(const PmxTickParams *p, int H, hipStream_t
 extern "C" hipError_t pmx_launch_rule_agent(const PmxTickParams *p, int H, int agent, hipStream_t st)
 {
     const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
-    const size_t lds = (p->layout_idx ? 32 + (size_t)(3 * PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)3 * H * PMX_RULE_BLOCK) * sizeof(uint32_t);
+    const size_t lds = (p->layout_idx ? 32 + (size_t)(3 * PMX_MAX_H_LDS + 32 + 16) * PMX_RULE_BLOCK : 32 + (size_t)(3 * H + 16) * PMX_RULE_BLOCK) * sizeof(uint32_t);
     if (p->dist) hipLaunchKernelGGL(pmx_rule_agent_kernel<true>, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p, agent);
     else hipLaunchKernelGGL(pmx_rule_agent_kernel<false>, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p, agent);
     return hipGetLastError();
@@ -1160,7 +1249,7 @@ extern "C" hipError_t pmx_launch_rule_agent(const PmxTickParams *p, int H, int a
 extern "C" hipError_t pmx_launch_successor(const PmxTickParams *p, int H, int agent, hipStream_t st)
 {
     const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
-    const size_t lds = (p->layout_idx ? 32 + (size_t)(3 * PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)3 * H * PMX_RULE_BLOCK) * sizeof(uint32_t);
+    const size_t lds = (p->layout_idx ? 32 + (size_t)(3 * PMX_MAX_H_LDS + 32 + 16) * PMX_RULE_BLOCK : 32 + (size_t)(3 * H + 16) * PMX_RULE_BLOCK) * sizeof(uint32_t);
     hipLaunchKernelGGL(pmx_successor_kernel, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p, agent);
     return hipGetLastError();
 }
@@ -1168,7 +1257,7 @@ extern "C" hipError_t pmx_launch_successor(const PmxTickParams *p, int H, int ag
 extern "C" hipError_t pmx_launch_reset(const PmxTickParams *p, int H, hipStream_t st)
 {
     const int blocks = (p->N + PMX_RULE_BLOCK - 1) / PMX_RULE_BLOCK;
-    const size_t lds = (p->layout_idx ? 32 + (size_t)(3 * PMX_MAX_H_LDS + 32) * PMX_RULE_BLOCK : 32 + (size_t)3 * H * PMX_RULE_BLOCK) * sizeof(uint32_t);
+    const size_t lds = (p->layout_idx ? 32 + (size_t)(3 * PMX_MAX_H_LDS + 32 + 16) * PMX_RULE_BLOCK : 32 + (size_t)(3 * H + 16) * PMX_RULE_BLOCK) * sizeof(uint32_t);
     hipLaunchKernelGGL(pmx_reset_kernel, dim3(blocks), dim3(PMX_RULE_BLOCK), lds, st, *p);
     return hipGetLastError();
 }
@@ -1253,3 +1342,15 @@ extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, const PmxExpan
     }
     return hipGetLastError();
 }
+
+#ifdef PMX_RULE_TIMING
+extern "C" int pmx_rule_ticks_read(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pmx_rule_ticks), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pmx_rule_ticks), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
