@@ -196,8 +196,9 @@ int pmx_profile_begin(pmx_env *env, int32_t max_launches);
 /* Launch tuning of the observation-expansion kernel for A/B measurements (no reference counterpart).  key: "expand_alt"
  * (1 = walk the planes in alternating directions from tick to tick, the default; 0 = always the same direction, so that every
  * byte reaches HBM even when the caller re-steps one buffer that partly fits the Infinity Cache), "expand_nt" (non-temporal
- * stores), "expand_lds_pad" (occupancy cap, bytes of dynamic LDS), "expand_lut".  value -1 restores the built-in choice.  The
- * same settings are read from the environment variables PMX_EXPAND_ALT / _NT / _LDS_PAD / _LUT once, at pmx_create. */
+ * stores), "expand_lds_pad" (occupancy cap, bytes of dynamic LDS), "expand_lut", "expand_wave_per_env" (one wave per env instead of
+ * one per (env, agent)).  value -1 restores the built-in choice.  The same settings are read from the environment variables
+ * PMX_EXPAND_ALT / _NT / _LDS_PAD / _LUT / _PER_ENV once, at pmx_create. */
 int pmx_set_tuning(pmx_env *env, const char *key, int32_t value);
 int pmx_profile_end(pmx_env *env, double *rule_ms, int32_t *rule_launches, double *expand_ms, int32_t *expand_launches);
 

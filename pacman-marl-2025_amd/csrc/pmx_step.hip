@@ -808,12 +808,17 @@ __device__ __forceinline__ uint4 pack_obs(uint32_t bits)
 template <int DT>
 __device__ __forceinline__ void patch_self(uint4 &v, int d, uint32_t carry)
 {
-    uint32_t *w = reinterpret_cast<uint32_t *>(&v);
+    // uint8: selects on the four members, never an index into the vector: the compiler turns the unrolled loop of
+    // `if (k == d >> 2) w[k] += ..` into a dynamically indexed access to a copy of the vector in SCRATCH memory, and every
+    // scratch reload waits for vmcnt(0), i.e. for all the plane stores in flight (the uint8 kernels did exactly that; the
+    // float32 / bfloat16 forms below compile to compares and selects and stay as they are)
     if (DT == 0) {
+        uint32_t *w = reinterpret_cast<uint32_t *>(&v);
         const uint32_t val = __float_as_uint((float)(1 + carry));
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (d == j) w[j] = val;
     } else if (DT == 1) {
+        uint32_t *w = reinterpret_cast<uint32_t *>(&v);
         const uint32_t val = __float_as_uint((float)(1 + carry)) >> 16;   // exact in bfloat16 for 1 + carry <= 256
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -821,8 +826,9 @@ __device__ __forceinline__ void patch_self(uint4 &v, int d, uint32_t carry)
             if (d == 2 * k + 1) w[k] = (w[k] & 0x0000FFFFu) | (val << 16);
         }
     } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) if ((d >> 2) == k) w[k] += carry << (8 * (d & 3));
+        const uint32_t add = carry << (8 * (d & 3));
+        const int k = d >> 2;
+        v.x += k == 0 ? add : 0u; v.y += k == 1 ? add : 0u; v.z += k == 2 ? add : 0u; v.w += k == 3 ? add : 0u;
     }
 }
 
@@ -963,7 +969,28 @@ __global__ __launch_bounds__(PMX_BLOCK) void pmx_expand_kernel(PmxExpandParams p
 // [4][8][H][W] block (4.9 KB of uint8 for smallCapture, contiguous: whole 128-byte lines except at the two ends, where
 // pmx_expand_kernel's 1 232-byte agent blocks split a line each).
 // ---------------------------------------------------------------------------------------------------------------
-template <int DT, bool NT>
+// EPW envs per wave, consecutive, with the NEXT env's snapshot words loaded while the current env's planes are streamed.
+// Measured and NOT used (EPW = 1 is what is launched): s_memtime (tools/rule_ticks.py, uint8) shows a wave spending ~7 k of its
+// ~14 k ticks on the snapshot loads, which queue behind the other waves' plane stores, yet two envs per wave with the prefetch ran
+// 20.4 us against 18.5 us -- as did a variant with 16 envs per block and cooperative, fully coalesced snapshot loads (24.9 us):
+// with half the waves the chip has fewer store streams in flight, and that costs more than the hidden latency gains.
+struct SnapWords { uint32_t food[4], pt[4], a_self[4], b_self[4]; };
+__device__ __forceinline__ void load_snap_words(SnapWords &s, const PmxExpandParams &p, long env, int lane, int H)
+{
+    const size_t N = (size_t)p.N;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const uint32_t *S = p.snap[a] + env;
+        s.food[a] = lane < H ? S[(size_t)lane * N] : 0u;
+        s.pt[a] = 0;
+        if (lane < 4) s.pt[a] = S[(size_t)PMX_W_AGENT_A(H, lane) * N];
+        else if (lane < 8) s.pt[a] = S[(size_t)PMX_W_CAPS(H, (lane - 4) >> 1) * N];
+        s.a_self[a] = S[(size_t)PMX_W_AGENT_A(H, a) * N];
+        s.b_self[a] = S[(size_t)PMX_W_AGENT_B(H, a) * N];
+    }
+}
+
+template <int DT, bool NT, int EPW>
 __global__ __launch_bounds__(PMX_BLOCK) void pmx_expand4_kernel(PmxExpandParams p)
 {
     constexpr int VEC = ObsVec<DT>::VEC;
@@ -986,89 +1013,125 @@ __global__ __launch_bounds__(PMX_BLOCK) void pmx_expand4_kernel(PmxExpandParams 
     const int lane = threadIdx.x & 63;
     const int W = p.lay_W, H = p.lay_H, HW = H * W;
     long blk = p.reverse ? (long)gridDim.x - 1 - (long)blockIdx.x : (long)blockIdx.x;
-    if ((p.N & 127) == 0) {
-        // XCD-aware order (blocks b, b + 8, .. share an XCD): the 16 envs whose SoA snapshot words share a 64-byte line are the
-        // four blocks 4k .. 4k+3; send them to one XCD
-        const long r = blk & 31;
-        blk = (blk & ~31L) + ((r & 7) << 2) + (r >> 3);
+    if ((p.N & (128 * EPW - 1)) == 0 && EPW <= 4) {
+        // XCD-aware order (blocks b, b + 8, .. share an XCD): the 16 envs whose SoA snapshot words share a 64-byte line are
+        // 4 / EPW consecutive blocks; send them to one XCD
+        constexpr int G = 4 / EPW;                            // blocks per line of 16 envs
+        const long r = blk & (8 * G - 1);
+        blk = (blk & ~(long)(8 * G - 1)) + (r & 7) * G + (r >> 3);
     }
-    const long env = blk * 4 + wave;
-    if (env >= p.N) return;
-    const size_t N = (size_t)p.N;
-    const PmxLayoutDev *L = p.lay + (p.layout_idx ? p.layout_idx[env] : 0);
-    // all four agents' snapshot words in flight together
-    uint32_t food[4], pt[4], a_self[4], b_self[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const uint32_t *S = p.snap[a] + env;
-        food[a] = lane < H ? S[(size_t)lane * N] : 0u;
-        pt[a] = 0;
-        if (lane < 4) pt[a] = S[(size_t)PMX_W_AGENT_A(H, lane) * N];
-        else if (lane < 8) pt[a] = S[(size_t)PMX_W_CAPS(H, (lane - 4) >> 1) * N];
-        a_self[a] = S[(size_t)PMX_W_AGENT_A(H, a) * N];
-        b_self[a] = S[(size_t)PMX_W_AGENT_B(H, a) * N];
-    }
+    const long env_first = (blk * 4 + wave) * EPW;
+    if (env_first >= p.N) return;
+#ifdef PMX_RULE_TIMING
+    unsigned long long last_ = __builtin_amdgcn_s_memtime();
+    const bool rec_ = (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x - 1) && threadIdx.x == 0;
+#define PMX_XTICK(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (rec_) atomicAdd(&pmx_rule_ticks[8 + i], now_ - last_); last_ = now_; } while (0)
+#else
+#define PMX_XTICK(i) do { } while (0)
+#endif
     const int n_words = (8 * HW + 31) >> 5;
     const int wall_words = (HW + 31) >> 5;
+    const int n_vec = 8 * HW / VEC;
+    SnapWords cur;
+    load_snap_words(cur, p, env_first, lane, H);              // all four agents' snapshot words in flight together
+#pragma unroll 1
+    for (int q = 0; q < EPW; ++q) {
+        const long env = env_first + q;
+        if (env >= p.N) break;
+        const PmxLayoutDev *L = p.lay + (p.layout_idx ? p.layout_idx[env] : 0);
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-        for (int k = lane; k < n_words + 1; k += 64) tab[wave][a][k] = k < wall_words ? L->wall_stream[k] : 0u;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    int fself[4];
-    uint32_t carry[4];
+        for (int a = 0; a < 4; ++a)
+            for (int k = lane; k < n_words + 1; k += 64) tab[wave][a][k] = k < wall_words ? L->wall_stream[k] : 0u;
+        const uint32_t hi_mask = L->hi_mask, lo_mask = L->lo_mask;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        PMX_XTICK(0);
+        int fself[4];
+        uint32_t carry[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        uint32_t *T = tab[wave][a];
-        if (lane < H) {
-            stream_or_row(T, (uint32_t)((6 * H + lane) * W), food[a] & L->hi_mask, W);
-            stream_or_row(T, (uint32_t)((7 * H + lane) * W), food[a] & L->lo_mask, W);
-        }
-        if (lane < 4) {
-            const int x = pt[a] & 0xFF, y = (pt[a] >> 8) & 0xFF;
-            const int plane = lane == a ? 1 : (((lane ^ a) == 2) ? 4 : 5);
-            const uint32_t off = (uint32_t)((plane * H + y) * W + x);
-            atomicOr(&T[off >> 5], 1u << (off & 31));
-        } else if (lane < 8) {
-            const uint32_t cxy = (pt[a] >> (16 * ((lane - 4) & 1))) & 0xFFFFu;
-            if (cxy != 0xFFFFu) {
-                const int x = cxy & 0xFF, y = cxy >> 8;
-                const int plane = (2 * x > W) ? 2 : 3;
+        for (int a = 0; a < 4; ++a) {
+            uint32_t *T = tab[wave][a];
+            if (lane < H) {
+                stream_or_row(T, (uint32_t)((6 * H + lane) * W), cur.food[a] & hi_mask, W);
+                stream_or_row(T, (uint32_t)((7 * H + lane) * W), cur.food[a] & lo_mask, W);
+            }
+            if (lane < 4) {
+                const int x = cur.pt[a] & 0xFF, y = (cur.pt[a] >> 8) & 0xFF;
+                const int plane = lane == a ? 1 : (((lane ^ a) == 2) ? 4 : 5);
                 const uint32_t off = (uint32_t)((plane * H + y) * W + x);
                 atomicOr(&T[off >> 5], 1u << (off & 31));
+            } else if (lane < 8) {
+                const uint32_t cxy = (cur.pt[a] >> (16 * ((lane - 4) & 1))) & 0xFFFFu;
+                if (cxy != 0xFFFFu) {
+                    const int x = cxy & 0xFF, y = cxy >> 8;
+                    const int plane = (2 * x > W) ? 2 : 3;
+                    const uint32_t off = (uint32_t)((plane * H + y) * W + x);
+                    atomicOr(&T[off >> 5], 1u << (off & 31));
+                }
+            }
+            carry[a] = (cur.b_self[a] >> 8) & 0xFFF;
+            fself[a] = (H + (int)((cur.a_self[a] >> 8) & 0xFF)) * W + (int)(cur.a_self[a] & 0xFF);
+        }
+        if (EPW > 1 && q + 1 < EPW && env + 1 < p.N) load_snap_words(cur, p, env + 1, lane, H);   // in flight behind the stores below
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        PMX_XTICK(1);
+
+        uint4 *out = reinterpret_cast<uint4 *>(p.obs) + (size_t)env * 4 * n_vec;
+        // U iterations of the store loop at a time: all their stream words are read first, then all look-up-table entries,
+        // then the stores are issued -- one LDS round trip per group instead of two per 16 bytes (a wave spent 1.2 k ticks per
+        // store instruction on these dependent reads)
+        constexpr int U = 5;
+        for (int base = 0; base < 4 * n_vec; base += 64 * U) {
+            uint32_t bits[U];
+            int ag[U];
+            uint32_t e0s[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int kk = base + 64 * u + lane;
+                const int a = (kk >= n_vec) + (kk >= 2 * n_vec) + (kk >= 3 * n_vec);
+                const int a_c = kk < 4 * n_vec ? a : 0;
+                const int k = kk < 4 * n_vec ? kk - a * n_vec : 0;
+                ag[u] = a_c;
+                e0s[u] = (uint32_t)k * VEC;
+                bits[u] = tab[wave][a_c][e0s[u] >> 5] >> (e0s[u] & 31);
+            }
+            uint4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (DT == 0) v[u] = *reinterpret_cast<const uint4 *>(&lut[(bits[u] & 15u) * 4]);
+                else if (DT == 1) v[u] = *reinterpret_cast<const uint4 *>(&lut[(bits[u] & 255u) * 4]);
+                else {
+                    const uint2 lo = *reinterpret_cast<const uint2 *>(&lut[(bits[u] & 255u) * 2]);
+                    const uint2 hi = *reinterpret_cast<const uint2 *>(&lut[((bits[u] >> 8) & 255u) * 2]);
+                    v[u] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int kk = base + 64 * u + lane;
+                const int a = ag[u];
+                const int fs = a == 0 ? fself[0] : (a == 1 ? fself[1] : (a == 2 ? fself[2] : fself[3]));
+                const uint32_t cr = a == 0 ? carry[0] : (a == 1 ? carry[1] : (a == 2 ? carry[2] : carry[3]));
+                const uint32_t d = (uint32_t)(fs - (int)e0s[u]);
+                if (d < (uint32_t)VEC) patch_self<DT>(v[u], (int)d, cr);
+                if (kk < 4 * n_vec) {
+                    if (NT) {
+                        __builtin_nontemporal_store(v[u].x, &out[kk].x); __builtin_nontemporal_store(v[u].y, &out[kk].y);
+                        __builtin_nontemporal_store(v[u].z, &out[kk].z); __builtin_nontemporal_store(v[u].w, &out[kk].w);
+                    } else {
+                        out[kk] = v[u];
+                    }
+                }
             }
         }
-        carry[a] = (b_self[a] >> 8) & 0xFFF;
-        fself[a] = (H + (int)((a_self[a] >> 8) & 0xFF)) * W + (int)(a_self[a] & 0xFF);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the tables are rebuilt for the next env
+        __builtin_amdgcn_wave_barrier();
+        PMX_XTICK(2);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    const int n_vec = 8 * HW / VEC;
-    uint4 *out = reinterpret_cast<uint4 *>(p.obs) + (size_t)env * 4 * n_vec;
-    for (int kk = lane; kk < 4 * n_vec; kk += 64) {
-        const int a = kk / n_vec, k = kk - a * n_vec;
-        const uint32_t e0 = (uint32_t)k * VEC;
-        const uint32_t bits = tab[wave][a][e0 >> 5] >> (e0 & 31);
-        uint4 v;
-        if (DT == 0) v = *reinterpret_cast<const uint4 *>(&lut[(bits & 15u) * 4]);
-        else if (DT == 1) v = *reinterpret_cast<const uint4 *>(&lut[(bits & 255u) * 4]);
-        else {
-            const uint2 lo = *reinterpret_cast<const uint2 *>(&lut[(bits & 255u) * 2]);
-            const uint2 hi = *reinterpret_cast<const uint2 *>(&lut[((bits >> 8) & 255u) * 2]);
-            v = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        }
-        const int fs = a == 0 ? fself[0] : (a == 1 ? fself[1] : (a == 2 ? fself[2] : fself[3]));
-        const uint32_t cr = a == 0 ? carry[0] : (a == 1 ? carry[1] : (a == 2 ? carry[2] : carry[3]));
-        const uint32_t d = (uint32_t)(fs - (int)e0);
-        if (d < (uint32_t)VEC) patch_self<DT>(v, (int)d, cr);
-        if (NT) {
-            __builtin_nontemporal_store(v.x, &out[kk].x); __builtin_nontemporal_store(v.y, &out[kk].y);
-            __builtin_nontemporal_store(v.z, &out[kk].z); __builtin_nontemporal_store(v.w, &out[kk].w);
-        } else {
-            out[kk] = v;
-        }
-    }
+#ifdef PMX_RULE_TIMING
+    if (rec_) atomicAdd(&pmx_rule_ticks[14], 1ull);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1303,11 +1366,12 @@ extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, const PmxExpan
     bool per_env = dtype == 2 && p->n_emit == 4 && p->single_agent < 0;
     if (tune && tune->per_env >= 0) per_env = tune->per_env != 0 && p->n_emit == 4 && p->single_agent < 0;
     if (per_env) {
-        const unsigned b4 = (unsigned)((p->N + 3) / 4);
+        constexpr int epw = 1;                                 // envs per wave (see pmx_expand4_kernel)
+        const unsigned b4 = (unsigned)((p->N + 4 * epw - 1) / (4 * epw));
 #define PMX_EXPAND4(DT, NTV)                                                                                              \
     do {                                                                                                                  \
-        if (ev0) hipExtLaunchKernelGGL((pmx_expand4_kernel<DT, NTV>), dim3(b4), dim3(PMX_BLOCK), 0, st, ev0, ev1, 0, *p);   \
-        else hipLaunchKernelGGL((pmx_expand4_kernel<DT, NTV>), dim3(b4), dim3(PMX_BLOCK), 0, st, *p);                      \
+        if (ev0) hipExtLaunchKernelGGL((pmx_expand4_kernel<DT, NTV, epw>), dim3(b4), dim3(PMX_BLOCK), 0, st, ev0, ev1, 0, *p); \
+        else hipLaunchKernelGGL((pmx_expand4_kernel<DT, NTV, epw>), dim3(b4), dim3(PMX_BLOCK), 0, st, *p);                 \
     } while (0)
         // the planes of these types fit the Infinity Cache up to a few hundred MB: ordinary stores there, streaming beyond
         const bool nt4 = (tune && tune->nt >= 0) ? tune->nt != 0 : bytes > ((size_t)200 << 20);

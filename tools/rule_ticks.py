@@ -9,7 +9,8 @@ from pmx import _lib
 
 lib = _lib.load()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-env = pmx.PmxVecEnv("smallCapture", n_envs=N, length=300, auto_reset=True, obs_dtype="float32", device="cuda:0", seed=1)
+DT = sys.argv[2] if len(sys.argv) > 2 else "float32"
+env = pmx.PmxVecEnv("smallCapture", n_envs=N, length=300, auto_reset=True, obs_dtype=DT, device="cuda:0", seed=1)
 env.reset()
 g = torch.Generator(device="cuda").manual_seed(0)
 acts = [torch.randint(0, 5, (N, 4), device="cuda", generator=g, dtype=torch.int8) for _ in range(16)]
@@ -27,4 +28,7 @@ names = ["issue_loads+ctx", "commit(wait loads)", "substep0+snap", "substep1+sna
 launches = buf[15]
 per = {names[i]: round(buf[i] / launches, 1) for i in range(8)}
 per["total_ticks"] = round(sum(buf[i] for i in range(8)) / launches, 1)
-print(json.dumps({"envs": N, "launches": int(launches), "s_memtime_ticks_per_launch_block0": per}))
+out = {"envs": N, "obs": DT, "launches": int(launches), "s_memtime_ticks_per_launch_block0": per}
+if buf[14]:
+    out["expand4_wave_ticks (3 sampled blocks)"] = {n: round(buf[8 + i] / buf[14], 1) for i, n in enumerate(["loads+table_init", "build", "stream"])}
+print(json.dumps(out))
