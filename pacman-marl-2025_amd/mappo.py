@@ -684,7 +684,12 @@ class PPOLearner:
         """loss.backward() with the gradient ending up in the flat float32 bucket (zeroed / accumulated the usual way, or
         copied from the flat bfloat16 gradient in one kernel)."""
         if self._w16 is None:
-            loss.backward()
+            # one gathering copy instead of loss.backward(): AccumulateGrad ADDS every parameter's gradient into its (zeroed) view
+            # of the bucket -- ~80 small kernels per step on this network, a quarter of the launches of the 512-sample step
+            grads = torch.autograd.grad(loss, self.bucket.params, allow_unused=True)
+            flat = [g.reshape(-1) if g is not None else torch.zeros(p.numel(), dtype=self.bucket.grad.dtype, device=self.bucket.grad.device)
+                    for g, p in zip(grads, self.bucket.params)]
+            torch.cat(flat, out=self.bucket.grad)
             return
         (g16,) = torch.autograd.grad(loss, (self._w16,))
         self.bucket.grad.copy_(g16)
@@ -714,11 +719,9 @@ class PPOLearner:
         if self._w16 is not None:
             loss, stats = self._loss_bf16_flat(obs, merged, act, old_logp, adv, ret, clip_eps, ent_coef)
         elif self.autocast_dtype is not None:
-            self.bucket.grad.zero_()
             with torch.autocast(device_type=dev_type, dtype=self.autocast_dtype):
                 loss, stats = ppo_loss(self.model, obs, merged, act, old_logp, adv, ret, clip_eps, ent_coef)
         else:
-            self.bucket.grad.zero_()
             loss, stats = ppo_loss(self.model, obs, merged, act, old_logp, adv, ret, clip_eps, ent_coef)
         self._backward_into_bucket(loss)
         if self.world_size > 1:
@@ -770,12 +773,10 @@ class PPOLearner:
                 loss, stats = self._loss_bf16_flat(i["obs"], i["merged"], i["act"], i["logp"], i["adv"], i["ret"],
                                                    self._g_sc[2], self._g_sc[3])
             elif self.autocast_dtype is not None:
-                self.bucket.grad.zero_()
                 with torch.autocast(device_type=dev.type, dtype=self.autocast_dtype):
                     loss, stats = ppo_loss(self.model, i["obs"], i["merged"], i["act"], i["logp"], i["adv"], i["ret"],
                                            self._g_sc[2], self._g_sc[3])
             else:
-                self.bucket.grad.zero_()
                 loss, stats = ppo_loss(self.model, i["obs"], i["merged"], i["act"], i["logp"], i["adv"], i["ret"],
                                        self._g_sc[2], self._g_sc[3])
             self._backward_into_bucket(loss)
