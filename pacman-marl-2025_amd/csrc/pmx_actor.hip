@@ -662,17 +662,27 @@ __global__ __launch_bounds__(256, 1) void pmx_actor_bwd_data_kernel(const char *
 // bias / GroupNorm-affine gradients: sum of the data kernel's per-block rows into the gradient buffer
 __global__ __launch_bounds__(256) void pmx_actor_sum_acc_kernel(const float *__restrict__ accpart, int n_rows, float *__restrict__ grad)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= NLAYER * 96) return;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int r = 0;
-    for (; r + 4 <= n_rows; r += 4) {
-        a0 += accpart[(size_t)r * (NLAYER * 96) + i], a1 += accpart[(size_t)(r + 1) * (NLAYER * 96) + i];
-        a2 += accpart[(size_t)(r + 2) * (NLAYER * 96) + i], a3 += accpart[(size_t)(r + 3) * (NLAYER * 96) + i];
+    // 32 columns x 8 row slices per block, slices added through LDS (a lone thread per column was a serial chain of n_rows / 4
+    // memory round trips: 53 us at 2 048 rows)
+    __shared__ float part[8][33];
+    const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + c;                               // NLAYER * 96 = 768 columns: 24 blocks
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int r = sl;
+    for (; r + 24 < n_rows; r += 32) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] += accpart[(size_t)(r + 8 * k) * (NLAYER * 96) + i];
     }
-    for (; r < n_rows; ++r) a0 += accpart[(size_t)r * (NLAYER * 96) + i];
-    const int l = i / 96, j = i - l * 96, kind = j >> 5, ch = j & 31;
-    grad[(kind == 0 ? GRAD_B : kind == 1 ? GRAD_GNW : GRAD_GNB) + l * 32 + ch] = (a0 + a1) + (a2 + a3);
+    for (; r < n_rows; r += 8) acc[0] += accpart[(size_t)r * (NLAYER * 96) + i];
+    part[sl][c] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (sl == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += part[k][c];
+        const int l = i / 96, j = i - l * 96, kind = j >> 5, ch = j & 31;
+        grad[(kind == 0 ? GRAD_B : kind == 1 ? GRAD_GNW : GRAD_GNB) + l * 32 + ch] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -956,7 +966,7 @@ int launch_bwd(const void *obs, const void *pack, const void *save, const void *
     const int grid_d = grid_for(B, 2);
     hipLaunchKernelGGL((pmx_actor_bwd_data_kernel<NT>), dim3(grid_d), dim3(256), lds_d, st, (const char *)pack, (const uint2 *)dfeat,
                        hs, ys, stt, da, sk, accpart, (int)B, H, W);
-    hipLaunchKernelGGL(pmx_actor_sum_acc_kernel, dim3(3), dim3(256), 0, st, (const float *)accpart, grid_d, grad);
+    hipLaunchKernelGGL(pmx_actor_sum_acc_kernel, dim3(NLAYER * 96 / 32), dim3(256), 0, st, (const float *)accpart, grid_d, grad);
     if (hipGetLastError() != hipSuccess) return PMX_ERR_HIP;
     // weight gradient: layers x sample chunks; about two blocks per CU in total, each wave at least a few samples
     const size_t lds_w = (size_t)4 * mp * 64;

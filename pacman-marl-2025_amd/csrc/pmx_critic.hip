@@ -369,19 +369,32 @@ __global__ __launch_bounds__(256, 1) void pmx_ffn_bwd_kernel(const uint4 *__rest
     if (threadIdx.x < 224) mine[G_B1 + threadIdx.x] = red[threadIdx.x] + red[224 + threadIdx.x] + red[448 + threadIdx.x] + red[672 + threadIdx.x];
 }
 
-// out[i] = sum over the partial rows (rows 1 .. n of the same buffer): the second stage of the gradient reductions
+// out[i] = sum over the partial rows (rows 1 .. n of the same buffer): the second stage of the gradient reductions.  A block
+// sums 32 columns with 8 slices of the rows side by side (128-byte segments per row, 8 loads in flight per thread) and adds the
+// slices through LDS: one thread per column walking all the rows alone was a serial chain of n / 8 memory round trips
+// (14.7 us per call at 512 rows, six calls per optimizer step).
 __global__ __launch_bounds__(256) void pmx_sum_rows_kernel(float *__restrict__ buf, int n_rows, int floats)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= floats) return;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int r = 1;
-    for (; r + 8 <= n_rows + 1; r += 8) {
+    __shared__ float part[8][33];
+    const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + c;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < floats) {
+        int r = 1 + sl;
+        for (; r + 24 <= n_rows; r += 32) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] += buf[(size_t)(r + k) * floats + i];
+            for (int k = 0; k < 4; ++k) acc[k] += buf[(size_t)(r + 8 * k) * floats + i];
+        }
+        for (; r <= n_rows; r += 8) acc[0] += buf[(size_t)r * floats + i];
     }
-    for (; r <= n_rows; ++r) acc[0] += buf[(size_t)r * floats + i];
-    buf[i] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    part[sl][c] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (sl == 0 && i < floats) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += part[k][c];
+        buf[i] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -736,7 +749,7 @@ extern "C" int pmx_ffn_backward(const void *x_dev, const void *dy_dev, const voi
     const unsigned blocks = (unsigned)(want < cap ? want : cap);
     hipLaunchKernelGGL(pmx_ffn_bwd_kernel, dim3(blocks), dim3(256), lds, st, (const uint4 *)x_dev, (const uint4 *)dy_dev,
                        (const char *)pack_dev, (uint4 *)dx_dev, grad_dev, (long)tokens, eps);
-    hipLaunchKernelGGL(pmx_sum_rows_kernel, dim3((G_FLOATS + 255) / 256), dim3(256), 0, st, grad_dev, (int)blocks, (int)G_FLOATS);
+    hipLaunchKernelGGL(pmx_sum_rows_kernel, dim3((G_FLOATS + 31) / 32), dim3(256), 0, st, grad_dev, (int)blocks, (int)G_FLOATS);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
 
@@ -765,7 +778,7 @@ int tok_backward(const void *a, const void *x, const void *dy, const void *pack,
     const unsigned blocks = (unsigned)(want < cap ? want : cap);
     hipLaunchKernelGGL((pmx_tok_bwd_kernel<NP, LN>), dim3(blocks), dim3(256), lds, st, (const uint4 *)a, (const uint4 *)x,
                        (const uint4 *)dy, (const char *)pack, (uint4 *)da, (uint4 *)dx, grad, (long)tokens, eps);
-    hipLaunchKernelGGL(pmx_sum_rows_kernel, dim3((TokPack<NP>::G_FLOATS + 255) / 256), dim3(256), 0, st, grad, (int)blocks, (int)TokPack<NP>::G_FLOATS);
+    hipLaunchKernelGGL(pmx_sum_rows_kernel, dim3((TokPack<NP>::G_FLOATS + 31) / 32), dim3(256), 0, st, grad, (int)blocks, (int)TokPack<NP>::G_FLOATS);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
 }   // namespace
