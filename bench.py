@@ -178,7 +178,8 @@ def ppo_probe(layname, dev, rank=0, world=1, dist=None, n_envs=16384, horizon=32
             "optimizer_steps_per_s": ref.get("optimizer_steps_per_s"), "samples_per_gpu_per_step": 512,
             "rollout_env_steps_per_s": big.get("rollout_env_steps_per_s"),
             "network": "MAPPOAgent: actor tower = one fused HIP forward kernel + two backward kernels on bf16 MFMA "
-                       "(csrc/pmx_actor.hip); critic = hand-written MFMA attention, add+LayerNorm kernels, hipBLASLt token GEMMs",
+                       "(csrc/pmx_actor.hip); critic batch-major / channels-last: MFMA attention, fused in-projection, out-projection + LayerNorm and "
+                       "feed-forward + LayerNorm kernels (csrc/pmx_critic.hip, pmx_train.hip); heads and the projector convolution on hipBLASLt / MIOpen",
             "reference_cpu": "0.49 s per optimizer step (2 steps/s) and about 80 env-steps/s end to end on 8 host cores, smallCapture "
                              "(tools/time_reference.py, profiles/r01_cpu_reference_ratio.json)"}
 

@@ -27,6 +27,10 @@ python3 $ROOT/tools/pmc_mfma.py /tmp/pmc_actor > $ROOT/$O/pmc_mfma_actor_critic.
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc_critic -- python3 $ROOT/tools/critic_bench.py --iters 5 > /tmp/pmc_critic.log 2>&1 || echo "pmc critic failed"
 python3 $ROOT/tools/pmc_mfma.py /tmp/pmc_critic >> $ROOT/$O/pmc_mfma_actor_critic.md 2>&1 || true
 cd $ROOT
+tools/actor_prof.sh 8192 > $O/actor_kernels_8192.txt 2>&1 || echo "actor prof failed"
+tools/actor_pmc.sh 8192 > $O/pmc_actor_wave_cycles.txt 2>&1 || echo "actor pmc failed"
+tools/critic_pmc.sh 8192 > $O/pmc_critic_wave_cycles.txt 2>&1 || echo "critic pmc failed"
+tools/step512_prof.sh 80 > $O/kernel_stats_train_step_mb512_graph.txt 2>&1 || echo "step512 prof failed"
 rm -f gpurun_out/traffic_new.json
 bash tools/pmc_pass.sh small16384 float32 f32 > $O/pmc_f32.log 2>&1 || echo "pmc f32 failed"
 bash tools/pmc_pass.sh small16384 uint8 u8 > $O/pmc_u8.log 2>&1 || echo "pmc u8 failed"
