@@ -266,6 +266,18 @@ int pmx_attn8_forward_layout(const void *qkv_dev, void *out_dev, float *lse_dev,
 int pmx_attn8_backward_layout(const void *qkv_dev, const void *out_dev, const void *dout_dev, const float *lse_dev, void *dqkv_dev,
                               int32_t S, int32_t B, int32_t batch_major, void *stream);
 
+/* The PPO minibatch objective (pacman_mappo_resnet.py:571-585) and its gradient with respect to the network outputs in one
+ * launch: logits_dev [B][5] float32 (logits_bf16 = 0) or bfloat16 (1); values_dev [BV] float32 with BV == B, or BV == B / 2 for
+ * paired minibatches (rows 2k, 2k + 1 are the two learners of one env-tick and share value k); act_dev [B] int64; old_logp,
+ * adv, ret [B] float32.  clip_eps / ent_coef come from the device pointers when those are not NULL (graph replay: the schedule
+ * changes them between replays), else from the host values.  Writes stats_dev[0..4] = policy loss, value loss, mean entropy,
+ * clip fraction, total loss (pg + vf_coef * vl - ent_coef * entropy), dlogits_dev [B][5] (the logits' type) and dvalues_dev
+ * [BV] float32 = d total / d outputs.  The advantages are normalised per minibatch with the unbiased standard deviation (:577). */
+int pmx_ppo_loss(const void *logits_dev, int32_t logits_bf16, const float *values_dev, const int64_t *act_dev,
+                 const float *old_logp_dev, const float *adv_dev, const float *ret_dev, int32_t B, int32_t BV,
+                 const float *clip_eps_dev, const float *ent_coef_dev, float clip_eps, float ent_coef, float vf_coef,
+                 float *stats_dev, void *dlogits_dev, float *dvalues_dev, void *stream);
+
 /* ---- The actor's convolutional tower as one forward and one backward kernel ------------------------------------------
  * MAPPOAgent.actor_backbone (pacman_mappo_resnet.py:104-113 with ResidualBlock :49-67):
  *   conv3x3(8->16) GELU conv3x3(16->32) GELU 3 x [conv3x3 GroupNorm(4) GELU conv3x3 GroupNorm(4) (+x) GELU], bf16 matrix-core

@@ -1200,3 +1200,136 @@ extern "C" int pmx_gn8cl_gelu_backward(const void *h, const void *res, const voi
     if (HW <= 192) PMX_GNCL_BWD(3); else if (HW <= 448) PMX_GNCL_BWD(7); else PMX_GNCL_BWD(16);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The minibatch objective of pacman_mappo_resnet.py:571-585 and its gradient with respect to the network outputs, as ONE
+// workgroup: log-softmax / entropy of the 5 logits, log-probability of the taken action, advantage normalisation with the
+// unbiased standard deviation of THIS minibatch (:577), clipped surrogate, value loss, entropy bonus, clip fraction.  In torch
+// this is ~60 small kernels forward and backward -- a fifth of the launches of the 512-sample optimizer step, which is a
+// chain of ~5 us kernels.  Sums are accumulated in float64 and reduced through LDS; the per-sample arithmetic is float32 in
+// the reference's order.  Gradients follow torch's rules: torch.min splits the gradient evenly on a tie (which is the whole
+// unclipped region, where clamp is the identity with gradient 1), clamp passes it on the closed interval.
+//   logits [B][5] (float32 or bfloat16), values [BV] float32 with BV == B or, for paired minibatches, BV == B / 2 (rows 2k and
+//   2k + 1 share value k); act int64; old_logp, adv, ret float32 [B].
+//   stats[0..4] = pg, vl, entropy, clip_frac, loss;  dlogits [B][5] in the logits' type, dvalues [BV] float32 (of loss).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ double block_sum_1024(double v, double *red)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();                       // red is reused from call to call
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w];
+    return t;
+}
+template <typename LT> __device__ __forceinline__ float logit_load(const LT *p);
+template <> __device__ __forceinline__ float logit_load<float>(const float *p) { return *p; }
+template <> __device__ __forceinline__ float logit_load<__hip_bfloat16>(const __hip_bfloat16 *p) { return __bfloat162float(*p); }
+template <typename LT> __device__ __forceinline__ void logit_store(LT *p, float v);
+template <> __device__ __forceinline__ void logit_store<float>(float *p, float v) { *p = v; }
+template <> __device__ __forceinline__ void logit_store<__hip_bfloat16>(__hip_bfloat16 *p, float v) { *p = __float2bfloat16(v); }
+}  // namespace
+
+template <typename LT>
+__global__ __launch_bounds__(1024) void pmx_ppo_loss_kernel(const LT *__restrict__ logits, const float *__restrict__ values,
+                                                           const int64_t *__restrict__ act, const float *__restrict__ old_logp,
+                                                           const float *__restrict__ adv, const float *__restrict__ ret, int B, int BV,
+                                                           const float *clip_dev, const float *ent_dev, float clip_host, float ent_host,
+                                                           float vf_coef, float *__restrict__ stats, LT *__restrict__ dlogits,
+                                                           float *__restrict__ dvalues)
+{
+    __shared__ double red[16];
+    const float clip_eps = clip_dev ? *clip_dev : clip_host, ent_coef = ent_dev ? *ent_dev : ent_host;
+    const int tid = threadIdx.x;
+    // advantage statistics: mean, then the unbiased variance around it (two passes, as torch.std)
+    double s = 0.0;
+    for (int i = tid; i < B; i += 1024) s += (double)adv[i];
+    const double mean = block_sum_1024(s, red) / (double)B;
+    double ss = 0.0;
+    for (int i = tid; i < B; i += 1024) { const double d = (double)adv[i] - mean; ss += d * d; }
+    const double var = block_sum_1024(ss, red) / (double)(B > 1 ? B - 1 : 1);
+    const float a_mean = (float)mean, a_den = (float)sqrt(var) + 1e-8f;
+    const float invB = 1.0f / (float)B;
+    const bool paired = BV * 2 == B;
+    double pg_s = 0.0, ent_s = 0.0, clip_s = 0.0, vl_s = 0.0;
+    for (int i = tid; i < B; i += 1024) {
+        float z[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) z[k] = logit_load<LT>(logits + (size_t)i * 5 + k);
+        const float zmax = fmaxf(fmaxf(fmaxf(z[0], z[1]), fmaxf(z[2], z[3])), z[4]);
+        float se = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) se += expf(z[k] - zmax);
+        const float lse = zmax + logf(se);
+        float nrm[5], p[5], H = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            nrm[k] = z[k] - lse;
+            p[k] = expf(nrm[k]);
+            H -= fmaxf(nrm[k], -3.4028234663852886e38f) * p[k];
+        }
+        const int a = (int)act[i];
+        const float logp = a == 0 ? nrm[0] : (a == 1 ? nrm[1] : (a == 2 ? nrm[2] : (a == 3 ? nrm[3] : nrm[4])));
+        const float na = (adv[i] - a_mean) / a_den;
+        const float ratio = expf(logp - old_logp[i]);
+        const float rc = fminf(fmaxf(ratio, 1.0f - clip_eps), 1.0f + clip_eps);
+        const float t1 = na * ratio, t2 = na * rc;
+        pg_s += (double)fminf(t1, t2);
+        ent_s += (double)H;
+        clip_s += fabsf(ratio - 1.0f) > clip_eps ? 1.0 : 0.0;
+        // d min(t1, t2) / d ratio
+        const float w1 = t1 < t2 ? 1.0f : (t1 == t2 ? 0.5f : 0.0f), w2 = t2 < t1 ? 1.0f : (t1 == t2 ? 0.5f : 0.0f);
+        const float in_range = (ratio >= 1.0f - clip_eps && ratio <= 1.0f + clip_eps) ? 1.0f : 0.0f;
+        const float dmin_dr = na * (w1 + w2 * in_range);
+        const float dlogp = -invB * dmin_dr * ratio;                      // d loss / d logp_i
+        const float dH = -ent_coef * invB;                                // d loss / d H_i
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const float g = dlogp * ((k == a ? 1.0f : 0.0f) - p[k]) + dH * (-p[k] * (nrm[k] + H));
+            logit_store<LT>(dlogits + (size_t)i * 5 + k, g);
+        }
+        const float v = values[paired ? (i >> 1) : i];
+        const float dv = v - ret[i];
+        vl_s += (double)(dv * dv);
+        if (!paired) dvalues[i] = vf_coef * invB * dv;
+    }
+    if (paired) {
+        for (int j = tid; j < BV; j += 1024) {
+            const float v = values[j];
+            dvalues[j] = vf_coef * invB * ((v - ret[2 * j]) + (v - ret[2 * j + 1]));
+        }
+    }
+    const double pg = -block_sum_1024(pg_s, red) / (double)B;
+    const double ent = block_sum_1024(ent_s, red) / (double)B;
+    const double cf = block_sum_1024(clip_s, red) / (double)B;
+    const double vl = 0.5 * block_sum_1024(vl_s, red) / (double)B;
+    if (tid == 0) {
+        stats[0] = (float)pg; stats[1] = (float)vl; stats[2] = (float)ent; stats[3] = (float)cf;
+        stats[4] = (float)pg + vf_coef * (float)vl - ent_coef * (float)ent;
+    }
+}
+
+extern "C" int pmx_ppo_loss(const void *logits_dev, int32_t logits_bf16, const float *values_dev, const int64_t *act_dev,
+                            const float *old_logp_dev, const float *adv_dev, const float *ret_dev, int32_t B, int32_t BV,
+                            const float *clip_eps_dev, const float *ent_coef_dev, float clip_eps, float ent_coef, float vf_coef,
+                            float *stats_dev, void *dlogits_dev, float *dvalues_dev, void *stream)
+{
+    if (!logits_dev || !values_dev || !act_dev || !old_logp_dev || !adv_dev || !ret_dev || !stats_dev || !dlogits_dev || !dvalues_dev)
+        return PMX_ERR_INVALID;
+    if (B < 1 || (BV != B && BV * 2 != B)) return PMX_ERR_INVALID;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (logits_bf16)
+        hipLaunchKernelGGL(pmx_ppo_loss_kernel<__hip_bfloat16>, dim3(1), dim3(1024), 0, st, (const __hip_bfloat16 *)logits_dev, values_dev, act_dev,
+                           old_logp_dev, adv_dev, ret_dev, (int)B, (int)BV, clip_eps_dev, ent_coef_dev, clip_eps, ent_coef, vf_coef, stats_dev,
+                           (__hip_bfloat16 *)dlogits_dev, dvalues_dev);
+    else
+        hipLaunchKernelGGL(pmx_ppo_loss_kernel<float>, dim3(1), dim3(1024), 0, st, (const float *)logits_dev, values_dev, act_dev, old_logp_dev,
+                           adv_dev, ret_dev, (int)B, (int)BV, clip_eps_dev, ent_coef_dev, clip_eps, ent_coef, vf_coef, stats_dev,
+                           (float *)dlogits_dev, dvalues_dev);
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}

@@ -500,6 +500,7 @@ class MAPPOAgent(nn.Module):
     fused_ffn = True        # use the fused feed-forward + LayerNorm kernels of the critic's encoder layers (bf16 on the GPU)
     fused_tower = True      # use the fused actor-tower kernels where they apply (bf16 on the GPU, supported board size)
     batch_major_critic = True   # run the critic channels-last / batch-major under bf16 autocast on the GPU (no transposing copies)
+    fused_loss = True       # the PPO objective and its gradient w.r.t. logits / values as one kernel on the GPU (pmx_ppo_loss)
     tower_pack = None       # packed tower parameters for inference, set by a caller that knows the weights are frozen
                             # (VecMAPPOTrainer.rollout); None = pack on every call
 
@@ -597,8 +598,55 @@ def canonicalize_action(action, is_red_agent):
     return _RED_ACTION_MAP[int(action)]
 
 
+class _PPOLossFn(torch.autograd.Function):
+    """pmx_ppo_loss: the objective's five scalars from the raw network outputs in one launch; the gradient with respect to the
+    logits and the values is computed in the same launch and handed out (scaled) by backward."""
+
+    @staticmethod
+    def forward(ctx, logits, values, act, old_logp, adv, ret, clip_eps, ent_coef, vf_coef):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        logits, values = logits.contiguous(), values.contiguous()
+        B, BV = logits.shape[0], values.shape[0]
+        stats = torch.empty(5, dtype=torch.float32, device=logits.device)
+        dlogits, dvalues = torch.empty_like(logits), torch.empty_like(values)
+
+        def scalar(v):
+            if isinstance(v, torch.Tensor):
+                assert v.is_cuda and v.dtype == torch.float32 and v.numel() == 1
+                return v.data_ptr(), 0.0
+            return None, float(v)
+        cp, ch = scalar(clip_eps)
+        ep, eh = scalar(ent_coef)
+        st = C.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream)
+        _lib.check(lib.pmx_ppo_loss(logits.data_ptr(), 1 if logits.dtype == torch.bfloat16 else 0, values.data_ptr(), act.contiguous().data_ptr(),
+                                    old_logp.contiguous().data_ptr(), adv.contiguous().data_ptr(), ret.contiguous().data_ptr(), B, BV, cp, ep,
+                                    ch, eh, float(vf_coef), stats.data_ptr(), dlogits.data_ptr(), dvalues.data_ptr(), st), "pmx_ppo_loss")
+        ctx.save_for_backward(dlogits, dvalues)
+        return stats
+
+    @staticmethod
+    def backward(ctx, gstats):
+        dlogits, dvalues = ctx.saved_tensors
+        g = gstats[4]                                     # only the total loss is an objective; the other entries are reports
+        return dlogits * g.to(dlogits.dtype), dvalues * g, None, None, None, None, None, None, None
+
+
+def _fused_loss_ok(model, obs, act, old_logp, adv, ret):
+    return (MAPPOAgent.fused_loss and isinstance(model, MAPPOAgent) and obs.is_cuda and act.dtype == torch.int64
+            and all(t.dtype == torch.float32 for t in (old_logp, adv, ret)) and act.shape[0] >= 2)
+
+
 def ppo_loss(model, obs, merged, act, old_logp, adv, ret, clip_eps, ent_coef, vf_coef=VF_COEF):
     """The minibatch objective of pacman_mappo_resnet.py:571-585.  Returns (loss, dict of detached scalars)."""
+    if _fused_loss_ok(model, obs, act, old_logp, adv, ret):
+        logits, vals = model.logits(obs), model.value(merged).float()
+        if logits.dtype not in (torch.float32, torch.bfloat16):
+            logits = logits.float()
+        stats = _PPOLossFn.apply(logits, vals, act, old_logp, adv, ret, clip_eps, ent_coef, vf_coef)
+        d = stats.detach()
+        return stats[4], {"pg": d[0], "vl": d[1], "entropy": d[2], "clip_frac": d[3], "loss": d[4]}
     vals, logp, ent = model.evaluate(obs, merged, act)
     if vals.shape[0] != ret.shape[0]:
         # paired minibatch: rows 2k and 2k+1 are the two learners of one env-tick and share ONE merged critic input

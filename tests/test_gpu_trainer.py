@@ -542,3 +542,70 @@ def test_batch_major_critic_matches_sequence_major_critic():
     for n in g0:
         rel = float((g0[n] - g1[n]).norm() / (g0[n].norm() + 1e-9))
         assert rel <= 5e-2, (n, rel)
+
+
+@pytest.mark.parametrize("B,paired,dtype", [(64, False, torch.float32), (1024, True, torch.float32), (4099 * 2, True, torch.float32),
+                                            (1024, True, torch.bfloat16), (3, False, torch.float32)])
+def test_fused_ppo_loss_matches_the_torch_objective(B, paired, dtype):
+    """pmx_ppo_loss against the torch formulas of ppo_loss (pacman_mappo_resnet.py:571-585) on the same logits / values:
+    the five scalars and the gradients with respect to the logits and the values, clipped and unclipped samples alike."""
+    from pmx import mappo
+    torch.manual_seed(B)
+    dev = "cuda"
+    logits = (torch.randn(B, 5, device=dev) * 2).to(dtype).requires_grad_(True)
+    BV = B // 2 if paired else B
+    values = torch.randn(BV, device=dev, requires_grad=True)
+    act = torch.randint(0, 5, (B,), device=dev)
+    old_logp = torch.log_softmax(torch.randn(B, 5, device=dev), -1).gather(1, act.view(-1, 1)).squeeze(1)
+    adv, ret = torch.randn(B, device=dev) * 3 + 0.5, torch.randn(B, device=dev)
+    clip_eps, ent_coef = 0.15, 0.02
+    stats = mappo._PPOLossFn.apply(logits, values, act, old_logp, adv, ret, clip_eps, ent_coef, mappo.VF_COEF)
+    stats[4].backward()
+    got = (stats.detach().double(), logits.grad.double(), values.grad.double())
+    # the reference formulas in float64 from the same (already rounded) inputs
+    z = logits.detach().double().requires_grad_(True)
+    v = values.detach().double().requires_grad_(True)
+    norm = z - z.logsumexp(-1, keepdim=True)
+    probs = torch.softmax(norm, -1)
+    logp = norm.gather(1, act.view(-1, 1)).squeeze(1)
+    ent = -(norm * probs).sum(-1)
+    vv = v.repeat_interleave(2) if paired else v
+    a = adv.double()
+    na = (a - a.mean()) / (a.std() + 1e-8)
+    ratio = (logp - old_logp.double()).exp()
+    pg = -torch.min(na * ratio, na * torch.clamp(ratio, 1 - clip_eps, 1 + clip_eps)).mean()
+    vl = 0.5 * ((vv - ret.double()) ** 2).mean()
+    loss = pg + mappo.VF_COEF * vl - ent_coef * ent.mean()
+    loss.backward()
+    cf = ((ratio - 1).abs() > clip_eps).double().mean()
+    ref = torch.stack([pg, vl, ent.mean(), cf, loss]).detach()
+    tol = 2e-5 if dtype == torch.float32 else 2e-5      # the inputs are identical; float32 arithmetic inside the kernel
+    assert torch.allclose(got[0], ref, rtol=tol, atol=tol), (got[0], ref)
+    gtol = 1e-5 if dtype == torch.float32 else 1e-2     # bfloat16 logits get a bfloat16 gradient
+    assert float((got[1] - z.grad).abs().max()) <= gtol * (float(z.grad.abs().max()) + 1e-12), float((got[1] - z.grad).abs().max())
+    assert float((got[2] - v.grad).abs().max()) <= 1e-5 * (float(v.grad.abs().max()) + 1e-12)
+
+
+def test_fused_ppo_loss_is_what_ppo_loss_uses_and_agrees_with_the_torch_path():
+    from pmx import mappo
+    torch.manual_seed(5)
+    H, W = 11, 14
+    m = mappo.MAPPOAgent((8, H, W)).cuda()
+    B = 64
+    obs = (torch.rand(B, 8, H, W, device="cuda") < 0.2).float()
+    merged = (torch.rand(B // 2, 8, H, W, device="cuda") < 0.2).float()
+    act = torch.randint(0, 5, (B,), device="cuda")
+    old_logp, adv, ret = -torch.rand(B, device="cuda") - 1, torch.randn(B, device="cuda"), torch.randn(B, device="cuda")
+    out = {}
+    for fused in (True, False):
+        mappo.MAPPOAgent.fused_loss = fused
+        m.zero_grad(set_to_none=True)
+        loss, st = mappo.ppo_loss(m, obs, merged, act, old_logp, adv, ret, 0.15, 0.02)
+        loss.backward()
+        out[fused] = (loss.detach().clone(), {k: v.clone() for k, v in st.items()}, [p.grad.clone() for p in m.parameters() if p.grad is not None])
+    mappo.MAPPOAgent.fused_loss = True
+    assert abs(float(out[True][0] - out[False][0])) <= 1e-5 * (abs(float(out[False][0])) + 1)
+    for k in out[True][1]:
+        assert abs(float(out[True][1][k] - out[False][1][k])) <= 1e-5 * (abs(float(out[False][1][k])) + 1), k
+    for a, b in zip(out[True][2], out[False][2]):
+        assert float((a - b).norm()) <= 2e-4 * (float(b.norm()) + 1e-9)
