@@ -278,6 +278,15 @@ int pmx_ppo_loss(const void *logits_dev, int32_t logits_bf16, const float *value
                  const float *clip_eps_dev, const float *ent_coef_dev, float clip_eps, float ent_coef, float vf_coef,
                  float *stats_dev, void *dlogits_dev, float *dvalues_dev, void *stream);
 
+/* Minibatch assembly in one launch: for t < n (n <= 8), dst[t] row r = src[t] row (idx[t][r / m] * m + r % m), m =
+ * rows_per_index[t], rows of row_bytes[t] bytes (a multiple of 4; multiples of 16 need 16-byte aligned bases), n_rows[t] output
+ * rows.  The arrays of pointers and sizes are HOST arrays; the pointers in them are device pointers.  (What
+ * pacman_mappo_resnet.py:560-569 does with `batch_indices` on its CPU tensors.) */
+int pmx_gather_rows(int32_t n, const void *const *src_dev, void *const *dst_dev, const int64_t *const *idx_dev,
+                    const int32_t *row_bytes, const int32_t *rows_per_index, const int64_t *n_rows, void *stream);
+/* n <= 8 float32 host values to consecutive device words, passed as kernel arguments (the scalars a replayed hipGraph reads). */
+int pmx_set_floats(float *dst_dev, const float *values, int32_t n, void *stream);
+
 /* ---- The actor's convolutional tower as one forward and one backward kernel ------------------------------------------
  * MAPPOAgent.actor_backbone (pacman_mappo_resnet.py:104-113 with ResidualBlock :49-67):
  *   conv3x3(8->16) GELU conv3x3(16->32) GELU 3 x [conv3x3 GroupNorm(4) GELU conv3x3 GroupNorm(4) (+x) GELU], bf16 matrix-core

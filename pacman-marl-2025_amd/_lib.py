@@ -83,6 +83,8 @@ PROTOTYPES = [
     ("pmx_attn8_forward", C.c_int, [_VP, _VP, _VP, _I32, _I32, _VP]),
     ("pmx_attn8_backward", C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _VP]),
     ("pmx_ppo_loss", C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _VP, _VP, C.c_float, C.c_float, C.c_float, _VP, _VP, _VP, _VP]),
+    ("pmx_gather_rows", C.c_int, [_I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    ("pmx_set_floats", C.c_int, [_VP, _VP, _I32, _VP]),
     ("pmx_attn8_forward_layout", C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP]),
     ("pmx_attn8_backward_layout", C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),
     ("pmx_colsum_bf16", C.c_int, [_VP, C.c_int64, _I32, _VP, _VP]),

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include <hip/hip_bf16.h>
 
@@ -1331,5 +1332,84 @@ extern "C" int pmx_ppo_loss(const void *logits_dev, int32_t logits_bf16, const f
         hipLaunchKernelGGL(pmx_ppo_loss_kernel<float>, dim3(1), dim3(1024), 0, st, (const float *)logits_dev, values_dev, act_dev, old_logp_dev,
                            adv_dev, ret_dev, (int)B, (int)BV, clip_eps_dev, ent_coef_dev, clip_eps, ent_coef, vf_coef, stats_dev,
                            (float *)dlogits_dev, dvalues_dev);
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Minibatch assembly for the replayed optimizer step: up to 8 row gathers dst[r] = src[idx[r / m] * m + r % m] in one launch
+// (m = rows per index: 2 for the per-learner tensors of a paired minibatch, whose index names an env-tick pair), straight into
+// the graph's static input tensors.  In torch this was six index kernels, the index arithmetic and six copies per step.
+// ---------------------------------------------------------------------------------------------------------------
+struct PmxGatherArgs {
+    const char *src[8];
+    char *dst[8];
+    const int64_t *idx[8];
+    int32_t row_bytes[8], rows_per_index[8];
+    int64_t n_rows[8];
+};
+__global__ __launch_bounds__(256) void pmx_gather_rows_kernel(PmxGatherArgs a)
+{
+    const int t = blockIdx.y;
+    const int rb = a.row_bytes[t], m = a.rows_per_index[t];
+    const char *src = a.src[t];
+    char *dst = a.dst[t];
+    const int64_t *idx = a.idx[t];
+    if ((rb & 15) == 0) {
+        const int per_row = rb >> 4;
+        const int64_t total = a.n_rows[t] * per_row;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+            const int64_t r = i / per_row;
+            const int c = (int)(i - r * per_row);
+            const int64_t s = idx[r / m] * m + r % m;
+            reinterpret_cast<uint4 *>(dst + r * rb)[c] = reinterpret_cast<const uint4 *>(src + s * rb)[c];
+        }
+    } else {
+        const int per_row = rb >> 2;                                      // rows of 4-byte words (checked by the host side)
+        const int64_t total = a.n_rows[t] * per_row;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+            const int64_t r = i / per_row;
+            const int c = (int)(i - r * per_row);
+            const int64_t s = idx[r / m] * m + r % m;
+            reinterpret_cast<uint32_t *>(dst + r * rb)[c] = reinterpret_cast<const uint32_t *>(src + s * rb)[c];
+        }
+    }
+}
+
+extern "C" int pmx_gather_rows(int32_t n, const void *const *src_dev, void *const *dst_dev, const int64_t *const *idx_dev,
+                               const int32_t *row_bytes, const int32_t *rows_per_index, const int64_t *n_rows, void *stream)
+{
+    if (n < 1 || n > 8 || !src_dev || !dst_dev || !idx_dev || !row_bytes || !rows_per_index || !n_rows) return PMX_ERR_INVALID;
+    PmxGatherArgs a;
+    memset(&a, 0, sizeof(a));
+    int64_t most = 0;
+    for (int t = 0; t < n; ++t) {
+        if (!src_dev[t] || !dst_dev[t] || !idx_dev[t] || row_bytes[t] < 4 || (row_bytes[t] & 3) || rows_per_index[t] < 1 || n_rows[t] < 0)
+            return PMX_ERR_INVALID;
+        if ((row_bytes[t] & 15) == 0 && (((uintptr_t)src_dev[t] | (uintptr_t)dst_dev[t]) & 15)) return PMX_ERR_INVALID;
+        a.src[t] = (const char *)src_dev[t]; a.dst[t] = (char *)dst_dev[t]; a.idx[t] = idx_dev[t];
+        a.row_bytes[t] = row_bytes[t]; a.rows_per_index[t] = rows_per_index[t]; a.n_rows[t] = n_rows[t];
+        const int64_t units = n_rows[t] * (row_bytes[t] >> ((row_bytes[t] & 15) == 0 ? 4 : 2));
+        most = units > most ? units : most;
+    }
+    if (most == 0) return PMX_OK;
+    int64_t blocks = (most + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pmx_gather_rows_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
+
+// up to 8 float32 values written to consecutive device words in one launch (the scalars a replayed graph reads: they travel
+// as kernel arguments, so no host staging buffer is involved)
+struct PmxFloats8 { float v[8]; };
+__global__ void pmx_set_floats_kernel(float *dst, PmxFloats8 f, int n)
+{
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = f.v[threadIdx.x];
+}
+extern "C" int pmx_set_floats(float *dst_dev, const float *values, int32_t n, void *stream)
+{
+    if (!dst_dev || !values || n < 1 || n > 8) return PMX_ERR_INVALID;
+    PmxFloats8 f;
+    for (int i = 0; i < 8; ++i) f.v[i] = i < n ? values[i] : 0.f;
+    hipLaunchKernelGGL(pmx_set_floats_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), dst_dev, f, (int)n);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }

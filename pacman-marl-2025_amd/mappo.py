@@ -814,6 +814,7 @@ class PPOLearner:
         # lr/bc1, 1/sqrt(bc2), clip_eps, ent_coef as device scalars
         self._g_sc = torch.zeros(4, dtype=torch.float32, device=dev)
         self._g_stats = None
+        self._g_acc = torch.zeros(6, dtype=torch.float32, device=dev)       # sums of (pg, vl, entropy, clip_frac, loss, grad_norm)
 
         def body():
             i = self._g_in
@@ -844,6 +845,10 @@ class PPOLearner:
             self.ema.mul_(EMA_DECAY).add_(p, alpha=1 - EMA_DECAY)
             self._refresh_bf16()
             stats["grad_norm"] = gn
+            # running sums of the step's reports, inside the graph: a caller that averages them over an update reads ONE tensor at
+            # the end instead of launching an add per report and step
+            self._g_acc_keys = tuple(stats.keys())
+            self._g_acc.add_(torch.stack([stats[k].float() for k in self._g_acc_keys]))
             return stats
 
         # warm up on a side stream (allocator, MIOpen solver search), restoring the optimizer state afterwards
@@ -867,9 +872,18 @@ class PPOLearner:
     def _set_graph_scalars(self, clip_eps, ent_coef, step):
         b1, b2 = self.betas
         bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
-        # fill_ passes the value as a kernel argument: stream-ordered, no host staging buffer that could be recycled
-        # while a copy is still in flight
-        for k, v in enumerate((self.lr / bc1, 1.0 / math.sqrt(bc2), clip_eps, ent_coef)):
+        vals = (self.lr / bc1, 1.0 / math.sqrt(bc2), clip_eps, ent_coef)
+        if self._g_sc.is_cuda:
+            # the four values travel as kernel arguments of ONE launch: stream-ordered, no host staging buffer that could be
+            # recycled while a copy is still in flight
+            import ctypes as C
+            from . import _lib
+            lib = _lib.load()
+            arr = (C.c_float * 4)(*[float(v) for v in vals])
+            st = C.c_void_p(torch.cuda.current_stream(self._g_sc.device).cuda_stream)
+            _lib.check(lib.pmx_set_floats(self._g_sc.data_ptr(), arr, 4, st), "pmx_set_floats")
+            return
+        for k, v in enumerate(vals):
             self._g_sc[k].fill_(float(v))
 
     def update_minibatch_graph(self, obs, merged, act, old_logp, adv, ret, clip_eps=CLIP_EPS, ent_coef=ENT_COEF_START):
@@ -877,6 +891,33 @@ class PPOLearner:
         i = self._g_in
         i["obs"].copy_(obs); i["merged"].copy_(merged); i["act"].copy_(act)
         i["logp"].copy_(old_logp); i["adv"].copy_(adv); i["ret"].copy_(ret)
+        self.step_count += 1
+        self._set_graph_scalars(clip_eps, ent_coef, self.step_count)
+        self._graph.replay()
+        return self._g_stats
+
+    def update_minibatch_graph_gather(self, sources, index, rows_per_index, clip_eps=CLIP_EPS, ent_coef=ENT_COEF_START):
+        """The replayed step with its minibatch assembled by ONE gather launch (pmx_gather_rows) straight into the graph's
+        static inputs: sources = the flat rollout tensors {obs, merged, act, logp, adv, ret} (rows = samples; merged rows =
+        env-ticks), index = int64 device indices, rows_per_index = {name: m} (2 for the per-learner tensors of a paired
+        minibatch whose index names env-tick pairs).  Returns the graph's stats tensors (valid until the next replay)."""
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        names = ("obs", "merged", "act", "logp", "adv", "ret")
+        n = len(names)
+        VP, I32, I64 = C.c_void_p * n, C.c_int32 * n, C.c_int64 * n
+        src, dst, idx, rb, m, nr = VP(), VP(), VP(), I32(), I32(), I64()
+        for k, name in enumerate(names):
+            s_t, d_t = sources[name], self._g_in[name]
+            assert s_t.is_contiguous() and d_t.is_contiguous() and s_t.dtype == d_t.dtype and s_t.shape[1:] == d_t.shape[1:], name
+            row = d_t[0].numel() * d_t.element_size() if d_t.dim() > 1 else d_t.element_size()
+            src[k], dst[k], idx[k] = s_t.data_ptr(), d_t.data_ptr(), index.data_ptr()
+            rb[k], m[k], nr[k] = row, rows_per_index[name], d_t.shape[0]
+            assert index.numel() * rows_per_index[name] == d_t.shape[0], (name, index.numel(), d_t.shape)
+        assert index.dtype == torch.int64 and index.is_contiguous()
+        st = C.c_void_p(torch.cuda.current_stream(index.device).cuda_stream)
+        _lib.check(lib.pmx_gather_rows(n, src, dst, idx, rb, m, nr, st), "pmx_gather_rows")
         self.step_count += 1
         self._set_graph_scalars(clip_eps, ent_coef, self.step_count)
         self._graph.replay()

@@ -85,6 +85,7 @@ class VecMAPPOTrainer:
         # the reference's; only the composition of the minibatches differs from the reference's independent shuffle of
         # agent samples (pacman_mappo_resnet.py:566-569).  False restores that shuffle.
         self.paired = bool(paired_minibatches) and algorithm == "mappo" and minibatch % 2 == 0
+        self.graph_gather = True     # replayed steps assemble their minibatch with pmx_gather_rows (False: torch indexing + copies)
         self.total_updates = total_updates
         H, W = self.env.layout.height, self.env.layout.width
         self.obs_shape = (8, H, W)
@@ -270,6 +271,9 @@ class VecMAPPOTrainer:
         agg = None
         steps = 0
         snap = None
+        # the one-launch minibatch gather needs the rollout tensors in the very type the graph's inputs have
+        gather = bool(self.use_graph and self.graph_gather and self.paired and self.device.type == "cuda" and S % self.minibatch == 0
+                      and self._net_in(obs[:1]).dtype == obs.dtype and self._net_in(merged[:1]).dtype == merged.dtype)
         if self.use_graph:      # a bad replay must not leave NaNs in the weights, the Adam moments and the EMA: keep a copy to go back to
             L = self.learner
             snap = [t.clone() for t in (L.bucket.data, L.exp_avg, L.exp_avg_sq, L.ema)] + [L.step_count]
@@ -281,13 +285,24 @@ class VecMAPPOTrainer:
             for s0 in range(0, S, self.minibatch):
                 if self.paired:
                     pr = pperm[s0 // 2:(s0 + self.minibatch) // 2]
-                    mb = torch.stack((2 * pr, 2 * pr + 1), dim=1).reshape(-1)      # rows 2k, 2k+1 = the two learners of pair k
                 else:
                     mb = perm[s0:s0 + self.minibatch]
                 if self.use_graph and not self._graph_ready:
                     self.learner.capture(self.minibatch, self.obs_shape, self._net_in(obs[:1]).dtype,
                                          clip_eps, ent_coef, merged_batch=self.minibatch // 2 if self.paired else None)
                     self._graph_ready = True
+                if gather:
+                    # replayed step, paired minibatch: one gather launch into the graph's inputs, reports summed inside the graph
+                    if steps == 0:
+                        self.learner._g_acc.zero_()
+                    self.learner.update_minibatch_graph_gather(
+                        {"obs": obs, "merged": merged, "act": act, "logp": logp, "adv": adv, "ret": ret}, pr,
+                        {"obs": 2, "merged": 1, "act": 2, "logp": 2, "adv": 2, "ret": 2}, clip_eps, ent_coef)
+                    steps += 1
+                    if max_steps is not None and steps >= max_steps:
+                        break
+                    continue
+                mb = torch.stack((2 * pr, 2 * pr + 1), dim=1).reshape(-1) if self.paired else mb   # rows 2k, 2k+1 = the two learners of pair k
                 step = self.learner.update_minibatch_graph if self.use_graph else self.learner.update_minibatch
                 critic_in = merged[pr] if self.paired else (merged[mb // 2] if self.algorithm == "mappo" else obs[mb])
                 st = step(self._net_in(obs[mb]), self._net_in(critic_in), act[mb], logp[mb], adv[mb], ret[mb], clip_eps, ent_coef)
@@ -297,6 +312,9 @@ class VecMAPPOTrainer:
                     break
             if max_steps is not None and steps >= max_steps:
                 break
+        if gather:
+            acc = self.learner._g_acc / steps
+            agg = {k: acc[i] * steps for i, k in enumerate(self.learner._g_acc_keys)}
         self.stats.update({k: v / steps for k, v in agg.items()})
         if self.use_graph and not bool(torch.isfinite(self.stats["grad_norm"]).item()):
             L = self.learner

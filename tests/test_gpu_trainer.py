@@ -609,3 +609,40 @@ def test_fused_ppo_loss_is_what_ppo_loss_uses_and_agrees_with_the_torch_path():
         assert abs(float(out[True][1][k] - out[False][1][k])) <= 1e-5 * (abs(float(out[False][1][k])) + 1), k
     for a, b in zip(out[True][2], out[False][2]):
         assert float((a - b).norm()) <= 2e-4 * (float(b.norm()) + 1e-9)
+
+
+def test_one_launch_minibatch_gather_equals_torch_indexing():
+    """The replayed optimizer step fed by pmx_gather_rows (paired minibatches, reports summed inside the graph) against the
+    same replay fed by torch indexing and copies: same random streams, so weights, EMA and the averaged reports agree (not bit
+    for bit: the tower's weight-gradient kernel adds with float atomics, whose order differs from run to run)."""
+    from pmx import trainer
+    res = {}
+    for gather in (True, False):
+        tr = trainer.VecMAPPOTrainer("tinyCapture", 64, horizon=8, minibatch=128, opponent="random", use_graph=True, seed=11)
+        tr.graph_gather = gather
+        tr.rollout(); tr.compute_gae(); tr.update()
+        res[gather] = (tr.learner.bucket.data.clone(), tr.learner.ema.clone(), {k: float(v) for k, v in tr.stats.items() if k in ("pg", "vl", "entropy", "loss", "grad_norm")})
+        tr.env.close()
+    for a, b in ((res[True][0], res[False][0]), (res[True][1], res[False][1])):
+        assert float((a - b).norm()) <= 2e-3 * float(b.norm()), float((a - b).norm() / b.norm())
+    for k in res[True][2]:
+        assert abs(res[True][2][k] - res[False][2][k]) <= 2e-2 * (abs(res[False][2][k]) + 1e-2), (k, res[True][2][k], res[False][2][k])
+
+
+def test_gather_rows_matches_index_select():
+    import ctypes as C
+    from pmx import _lib
+    lib = _lib.load()
+    torch.manual_seed(2)
+    src_a = torch.randint(0, 255, (4096, 8, 7, 20), dtype=torch.uint8, device="cuda")      # 1 120-byte rows
+    src_b = torch.randn(4096, device="cuda")
+    idx = torch.randperm(2048, device="cuda")[:100]
+    dst_a = torch.empty(200, 8, 7, 20, dtype=torch.uint8, device="cuda")
+    dst_b = torch.empty(100, device="cuda")
+    n = 2
+    VP, I32, I64 = C.c_void_p * n, C.c_int32 * n, C.c_int64 * n
+    rc = lib.pmx_gather_rows(n, VP(src_a.data_ptr(), src_b.data_ptr()), VP(dst_a.data_ptr(), dst_b.data_ptr()), VP(idx.data_ptr(), idx.data_ptr()),
+                             I32(1120, 4), I32(2, 1), I64(200, 100), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    rows = torch.stack((2 * idx, 2 * idx + 1), 1).reshape(-1)
+    assert torch.equal(dst_a, src_a[rows]) and torch.equal(dst_b, src_b[idx])
