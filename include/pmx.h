@@ -287,6 +287,15 @@ int pmx_gather_rows(int32_t n, const void *const *src_dev, void *const *dst_dev,
 /* n <= 8 float32 host values to consecutive device words, passed as kernel arguments (the scalars a replayed hipGraph reads). */
 int pmx_set_floats(float *dst_dev, const float *values, int32_t n, void *stream);
 
+/* clip_grad_norm_(max_norm) -> Adam (no weight decay, no amsgrad) -> EMA on flat float32 buffers of n elements, two launches
+ * (pacman_mappo_resnet.py:587-595).  scratch_dev: PMX_OPT_PARTIALS doubles.  lr / (1 - beta1^t) and 1 / sqrt(1 - beta2^t) are read
+ * from scalars_dev[0..1] when it is not NULL (graph replay), else taken from the host arguments.  grad_dev is left clipped;
+ * norm_out_dev (may be NULL) receives the gradient's 2-norm before clipping. */
+#define PMX_OPT_PARTIALS 1024
+int pmx_clip_adam_ema(float *grad_dev, float *param_dev, float *exp_avg_dev, float *exp_avg_sq_dev, float *ema_dev, int64_t n,
+                      double *scratch_dev, const float *scalars_dev, float lr_over_bc1, float rsqrt_bc2, float beta1, float beta2,
+                      float eps, float max_norm, float ema_decay, float *norm_out_dev, void *stream);
+
 /* ---- The actor's convolutional tower as one forward and one backward kernel ------------------------------------------
  * MAPPOAgent.actor_backbone (pacman_mappo_resnet.py:104-113 with ResidualBlock :49-67):
  *   conv3x3(8->16) GELU conv3x3(16->32) GELU 3 x [conv3x3 GroupNorm(4) GELU conv3x3 GroupNorm(4) (+x) GELU], bf16 matrix-core

@@ -15,6 +15,7 @@ LN32_PARTIAL_ROWS = 2048
 ACTOR_PACK_BYTES = 297984
 ACTOR_GRAD_FLOATS = 74496
 GRAD_PARTIAL_ROWS = 512
+OPT_PARTIALS = 1024                # PMX_OPT_PARTIALS: doubles of scratch pmx_clip_adam_ema needs
 FFN_PACK_BYTES = 33664
 FFN_GRAD_FLOATS = 8416
 TOK96_PACK_BYTES, TOK96_GRAD_FLOATS = 12928, 3232
@@ -83,6 +84,8 @@ PROTOTYPES = [
     ("pmx_attn8_forward", C.c_int, [_VP, _VP, _VP, _I32, _I32, _VP]),
     ("pmx_attn8_backward", C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _VP]),
     ("pmx_ppo_loss", C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _VP, _VP, C.c_float, C.c_float, C.c_float, _VP, _VP, _VP, _VP]),
+    ("pmx_clip_adam_ema", C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int64, _VP, _VP, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                    C.c_float, C.c_float, _VP, _VP]),
     ("pmx_gather_rows", C.c_int, [_I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     ("pmx_set_floats", C.c_int, [_VP, _VP, _I32, _VP]),
     ("pmx_attn8_forward_layout", C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP]),

@@ -1413,3 +1413,81 @@ extern "C" int pmx_set_floats(float *dst_dev, const float *values, int32_t n, vo
     hipLaunchKernelGGL(pmx_set_floats_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), dst_dev, f, (int)n);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The tail of the optimizer step on the flat buffers (pacman_mappo_resnet.py:587-595): clip_grad_norm_(0.5) -> Adam(eps 1e-5,
+// no weight decay, no amsgrad) -> EMA 0.995, as two launches instead of ~18 elementwise / reduction kernels over the 2.6 M
+// parameters.  Launch 1: per-block sums of g^2 in float64.  Launch 2: every block adds those partial sums itself (<= 1024 of
+// them), so the global norm and the clip factor need no third launch; then, per element, torch's formulas in float32:
+//   g *= min(1, max_norm / (norm + 1e-6));  m = m + (1 - b1)(g - m);  v = b2 v + (1 - b2) g g;
+//   p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps);  ema = decay * ema + (1 - decay) * p.
+// lr / bc1 and 1 / sqrt(bc2) come from two device floats when `sc_dev` is given (graph replay), else from the host values.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pmx_sqsum_partial_kernel(const float *__restrict__ g, long n, double *__restrict__ partial)
+{
+    __shared__ double red[4];
+    double s = 0.0;
+    const long n4 = n >> 2;
+    const float4 *g4 = reinterpret_cast<const float4 *>(g);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = g4[i];
+        s += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[(n4 << 2) + threadIdx.x]; s += (double)v * v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void pmx_adam_ema_kernel(float *__restrict__ g, float *__restrict__ p, float *__restrict__ m,
+                                                           float *__restrict__ v, float *__restrict__ ema, long n,
+                                                           const double *__restrict__ partial, int n_partial, const float *sc_dev,
+                                                           float lr_bc1_host, float rsqrt_bc2_host, float b1, float b2, float eps,
+                                                           float max_norm, float decay, float *__restrict__ norm_out)
+{
+    __shared__ double red[4];
+    __shared__ float s_scale;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n_partial; i += 256) s += partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
+        s_scale = fminf(max_norm / (norm + 1e-6f), 1.0f);
+        if (blockIdx.x == 0 && norm_out) *norm_out = norm;
+    }
+    __syncthreads();
+    const float scale = s_scale;
+    const float lr_bc1 = sc_dev ? sc_dev[0] : lr_bc1_host, rsqrt_bc2 = sc_dev ? sc_dev[1] : rsqrt_bc2_host;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i] * scale;
+        const float mi = m[i] + (1.0f - b1) * (gi - m[i]);
+        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+        const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
+        const float pi = p[i] - lr_bc1 * (mi / denom);
+        g[i] = gi; m[i] = mi; v[i] = vi; p[i] = pi;
+        ema[i] = ema[i] * decay + pi * (1.0f - decay);
+    }
+}
+
+extern "C" int pmx_clip_adam_ema(float *grad_dev, float *param_dev, float *exp_avg_dev, float *exp_avg_sq_dev, float *ema_dev, int64_t n,
+                                 double *scratch_dev, const float *scalars_dev, float lr_over_bc1, float rsqrt_bc2, float beta1, float beta2,
+                                 float eps, float max_norm, float ema_decay, float *norm_out_dev, void *stream)
+{
+    if (!grad_dev || !param_dev || !exp_avg_dev || !exp_avg_sq_dev || !ema_dev || !scratch_dev || n < 1) return PMX_ERR_INVALID;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > PMX_OPT_PARTIALS) blocks = PMX_OPT_PARTIALS;
+    hipLaunchKernelGGL(pmx_sqsum_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)grad_dev, (long)n, scratch_dev);
+    int64_t b2k = (n + 255) / 256;
+    if (b2k > 2048) b2k = 2048;
+    hipLaunchKernelGGL(pmx_adam_ema_kernel, dim3((unsigned)b2k), dim3(256), 0, st, grad_dev, param_dev, exp_avg_dev, exp_avg_sq_dev, ema_dev, (long)n,
+                       (const double *)scratch_dev, (int)blocks, scalars_dev, lr_over_bc1, rsqrt_bc2, beta1, beta2, eps, max_norm, ema_decay,
+                       norm_out_dev);
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}

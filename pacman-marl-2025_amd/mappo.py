@@ -762,6 +762,35 @@ class PPOLearner:
         denom = (self.exp_avg_sq.sqrt() / math.sqrt(bc2)).add_(self.eps)
         p.addcdiv_(self.exp_avg, denom, value=-self.lr / bc1)
 
+    fused_optimizer = True   # clip + Adam + EMA as two launches on the GPU (pmx_clip_adam_ema) instead of ~18 torch kernels
+
+    def _fused_tail(self, scalars_dev=None):
+        """clip_grad_norm_ -> Adam -> EMA through pmx_clip_adam_ema; returns the gradient norm (a 0-dim device tensor).  With
+        scalars_dev the bias-corrected step sizes are read from that device tensor (graph replay), else computed here from
+        step_count, which the caller has already advanced."""
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        dev = self.bucket.data.device
+        if getattr(self, "_opt_scratch", None) is None:
+            self._opt_scratch = torch.empty(_lib.OPT_PARTIALS, dtype=torch.float64, device=dev)
+            self._opt_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        b1, b2 = self.betas
+        if scalars_dev is None:
+            bc1, bc2 = 1 - b1 ** self.step_count, 1 - b2 ** self.step_count
+            sp, a, b = None, self.lr / bc1, 1.0 / math.sqrt(bc2)
+        else:
+            sp, a, b = scalars_dev.data_ptr(), 0.0, 0.0
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.pmx_clip_adam_ema(self.bucket.grad.data_ptr(), self.bucket.data.data_ptr(), self.exp_avg.data_ptr(),
+                                         self.exp_avg_sq.data_ptr(), self.ema.data_ptr(), self.bucket.numel, self._opt_scratch.data_ptr(), sp,
+                                         a, b, b1, b2, self.eps, MAX_GRAD_NORM, EMA_DECAY, self._opt_norm.data_ptr(), st), "pmx_clip_adam_ema")
+        return self._opt_norm[0]
+
+    def _use_fused_tail(self):
+        return (self.fused_optimizer and self.bucket.data.is_cuda and self.bucket.data.dtype == torch.float32
+                and self.bucket.grad.is_contiguous() and self.bucket.data.is_contiguous())
+
     def update_minibatch(self, obs, merged, act, old_logp, adv, ret, clip_eps=CLIP_EPS, ent_coef=ENT_COEF_START):
         dev_type = self.bucket.data.device.type
         if self._w16 is not None:
@@ -779,10 +808,14 @@ class PPOLearner:
         # clip_grad_norm_(parameters, 0.5): 2-norm of the per-tensor 2-norms (the reference's summation order; a single
         # fp32 reduction over the 2.6 M-element flat buffer is measurably less accurate on the CPU), then scale by
         # max_norm / (norm + 1e-6) if that is < 1
-        gn = torch.linalg.vector_norm(torch.stack(torch._foreach_norm([p.grad for p in self.bucket.params])))
-        self.bucket.grad.mul_(torch.clamp(MAX_GRAD_NORM / (gn + 1e-6), max=1.0))
-        self._adam_step()
-        self.ema.mul_(EMA_DECAY).add_(self.bucket.data, alpha=1 - EMA_DECAY)
+        if self._use_fused_tail():
+            self.step_count += 1
+            gn = self._fused_tail().clone()
+        else:
+            gn = torch.linalg.vector_norm(torch.stack(torch._foreach_norm([p.grad for p in self.bucket.params])))
+            self.bucket.grad.mul_(torch.clamp(MAX_GRAD_NORM / (gn + 1e-6), max=1.0))
+            self._adam_step()
+            self.ema.mul_(EMA_DECAY).add_(self.bucket.data, alpha=1 - EMA_DECAY)
         self._refresh_bf16()
         stats["grad_norm"] = gn.detach()
         return stats
@@ -833,16 +866,19 @@ class PPOLearner:
                 import torch.distributed as dist
                 dist.all_reduce(self.bucket.grad, op=dist.ReduceOp.SUM, group=self.pg)
                 self.bucket.grad.div_(self.world_size)
-            self._g_norms = torch.stack(torch._foreach_norm([p.grad for p in self.bucket.params]))   # kept: per-tensor norms
-            gn = torch.linalg.vector_norm(self._g_norms)
-            self.bucket.grad.mul_(torch.clamp(MAX_GRAD_NORM / (gn + 1e-6), max=1.0))
-            b1, b2 = self.betas
-            g, p = self.bucket.grad, self.bucket.data
-            self.exp_avg.lerp_(g, 1 - b1)
-            self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
-            denom = (self.exp_avg_sq.sqrt() * self._g_sc[1]).add_(self.eps)
-            p.sub_(self.exp_avg / denom * self._g_sc[0])
-            self.ema.mul_(EMA_DECAY).add_(p, alpha=1 - EMA_DECAY)
+            if self._use_fused_tail():
+                gn = self._fused_tail(self._g_sc)
+            else:
+                self._g_norms = torch.stack(torch._foreach_norm([p.grad for p in self.bucket.params]))   # kept: per-tensor norms
+                gn = torch.linalg.vector_norm(self._g_norms)
+                self.bucket.grad.mul_(torch.clamp(MAX_GRAD_NORM / (gn + 1e-6), max=1.0))
+                b1, b2 = self.betas
+                g, p = self.bucket.grad, self.bucket.data
+                self.exp_avg.lerp_(g, 1 - b1)
+                self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
+                denom = (self.exp_avg_sq.sqrt() * self._g_sc[1]).add_(self.eps)
+                p.sub_(self.exp_avg / denom * self._g_sc[0])
+                self.ema.mul_(EMA_DECAY).add_(p, alpha=1 - EMA_DECAY)
             self._refresh_bf16()
             stats["grad_norm"] = gn
             # running sums of the step's reports, inside the graph: a caller that averages them over an update reads ONE tensor at

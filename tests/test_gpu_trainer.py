@@ -646,3 +646,33 @@ def test_gather_rows_matches_index_select():
     assert rc == 0
     rows = torch.stack((2 * idx, 2 * idx + 1), 1).reshape(-1)
     assert torch.equal(dst_a, src_a[rows]) and torch.equal(dst_b, src_b[idx])
+
+
+def test_fused_clip_adam_ema_matches_the_torch_ops():
+    """pmx_clip_adam_ema against the torch sequence it replaces (clip by the global norm, Adam's single-tensor update, EMA) over
+    several steps with gradients on both sides of the clip threshold."""
+    from pmx import mappo
+    torch.manual_seed(0)
+    res = {}
+    for fused in (True, False):
+        torch.manual_seed(1)
+        m = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.Linear(53, 11)).cuda()
+        L = mappo.PPOLearner(m, lr=3e-4)
+        L.fused_optimizer = fused
+        norms = []
+        for step in range(6):
+            g = torch.Generator(device="cuda").manual_seed(100 + step)
+            L.bucket.grad.copy_(torch.randn(L.bucket.numel, device="cuda", generator=g) * (0.001 if step % 2 else 0.05))
+            if L._use_fused_tail():
+                L.step_count += 1
+                norms.append(float(L._fused_tail()))
+            else:
+                gn = torch.linalg.vector_norm(torch.stack(torch._foreach_norm([p.grad for p in L.bucket.params])))
+                L.bucket.grad.mul_(torch.clamp(mappo.MAX_GRAD_NORM / (gn + 1e-6), max=1.0))
+                L._adam_step()
+                L.ema.mul_(mappo.EMA_DECAY).add_(L.bucket.data, alpha=1 - mappo.EMA_DECAY)
+                norms.append(float(gn))
+        res[fused] = (L.bucket.data.clone(), L.exp_avg.clone(), L.exp_avg_sq.clone(), L.ema.clone(), L.bucket.grad.clone(), norms)
+    for a, b, name in zip(res[True][:5], res[False][:5], ("param", "exp_avg", "exp_avg_sq", "ema", "clipped grad")):
+        assert torch.allclose(a, b, rtol=2e-5, atol=1e-7), (name, float((a - b).abs().max()))
+    assert all(abs(x - y) <= 1e-5 * y for x, y in zip(res[True][5], res[False][5]))

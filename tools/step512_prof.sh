@@ -3,7 +3,7 @@
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_512
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_512 -- python3 $ROOT/tools/step512_prof.py 200 > /tmp/prof_512.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_512 -- python3 $ROOT/tools/step512_prof.py 190 16384 8 > /tmp/prof_512.log 2>&1
 tail -1 /tmp/prof_512.log
 cd $ROOT
 python tools/prof_summary.py $(find /tmp/prof_512 -name "*kernel_stats.csv" | head -1) "" ${1:-60}
