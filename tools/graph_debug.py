@@ -33,9 +33,8 @@ def main():
     ap.add_argument("--gc", default="auto", choices=["auto", "off", "every"], help="Python cyclic GC: default, disabled, or collect before every replay")
     ap.add_argument("--keep", action="store_true", help="keep the token_linear backward tensors of the captured run for inspection")
     args = ap.parse_args()
-    from pmx import mappo as _mappo_for_switch
-_mappo_for_switch.PPOLearner.fused_optimizer = False     # this tool inspects the per-tensor norms of the torch path
-from pmx import mappo
+    from pmx import mappo
+    mappo.PPOLearner.fused_optimizer = False     # this tool inspects the per-tensor norms of the torch path
     off = set(filter(None, args.disable.split(",")))
     if "attn" in off:
         def sdpa(qkv):
