@@ -296,6 +296,12 @@ int pmx_clip_adam_ema(float *grad_dev, float *param_dev, float *exp_avg_dev, flo
                       double *scratch_dev, const float *scalars_dev, float lr_over_bc1, float rsqrt_bc2, float beta1, float beta2,
                       float eps, float max_norm, float ema_decay, float *norm_out_dev, void *stream);
 
+/* n contiguous device tensors (float32, or bfloat16 where src_is_bf16[t]) copied / widened into dst_dev at element offsets
+ * dst_offset[t], count[t] elements each, one launch per 64 tensors: the parameter gradients of a step into the flat float32
+ * gradient bucket.  The four arrays are HOST arrays. */
+int pmx_flatten_to_f32(int32_t n, const void *const *src_dev, const uint8_t *src_is_bf16, const int64_t *dst_offset,
+                       const int32_t *count, float *dst_dev, void *stream);
+
 /* ---- The actor's convolutional tower as one forward and one backward kernel ------------------------------------------
  * MAPPOAgent.actor_backbone (pacman_mappo_resnet.py:104-113 with ResidualBlock :49-67):
  *   conv3x3(8->16) GELU conv3x3(16->32) GELU 3 x [conv3x3 GroupNorm(4) GELU conv3x3 GroupNorm(4) (+x) GELU], bf16 matrix-core

@@ -1491,3 +1491,51 @@ extern "C" int pmx_clip_adam_ema(float *grad_dev, float *param_dev, float *exp_a
                        norm_out_dev);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The parameter gradients of one optimizer step -- float32 or bfloat16 tensors, wherever autograd left them -- into the flat
+// float32 bucket in ONE launch (torch.cat needs one dtype, i.e. a cast kernel per bfloat16 gradient first, and three launches
+// for ~55 inputs).  blockIdx.y = tensor.
+// ---------------------------------------------------------------------------------------------------------------
+#define PMX_FLATTEN_MAX 64
+struct PmxFlattenArgs {
+    const void *src[PMX_FLATTEN_MAX];
+    int64_t off[PMX_FLATTEN_MAX];
+    int32_t count[PMX_FLATTEN_MAX];
+    uint8_t bf16[PMX_FLATTEN_MAX];
+};
+__global__ __launch_bounds__(256) void pmx_flatten_f32_kernel(PmxFlattenArgs a, float *__restrict__ dst)
+{
+    const int t = blockIdx.y;
+    const int n = a.count[t];
+    float *d = dst + a.off[t];
+    if (a.bf16[t]) {
+        const uint16_t *s = reinterpret_cast<const uint16_t *>(a.src[t]);
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) d[i] = __uint_as_float((uint32_t)s[i] << 16);
+    } else {
+        const float *s = reinterpret_cast<const float *>(a.src[t]);
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) d[i] = s[i];
+    }
+}
+extern "C" int pmx_flatten_to_f32(int32_t n, const void *const *src_dev, const uint8_t *src_is_bf16, const int64_t *dst_offset,
+                                  const int32_t *count, float *dst_dev, void *stream)
+{
+    if (n < 1 || !src_dev || !src_is_bf16 || !dst_offset || !count || !dst_dev) return PMX_ERR_INVALID;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    for (int base = 0; base < n; base += PMX_FLATTEN_MAX) {
+        const int m = n - base < PMX_FLATTEN_MAX ? n - base : PMX_FLATTEN_MAX;
+        PmxFlattenArgs a;
+        memset(&a, 0, sizeof(a));
+        int most = 0;
+        for (int t = 0; t < m; ++t) {
+            if (!src_dev[base + t] || count[base + t] < 0 || dst_offset[base + t] < 0) return PMX_ERR_INVALID;
+            a.src[t] = src_dev[base + t]; a.off[t] = dst_offset[base + t]; a.count[t] = count[base + t]; a.bf16[t] = src_is_bf16[base + t] ? 1 : 0;
+            most = count[base + t] > most ? count[base + t] : most;
+        }
+        int blocks = (most + 2047) / 2048;                     // ~8 elements per thread for the largest tensor
+        if (blocks < 1) blocks = 1;
+        if (blocks > 512) blocks = 512;
+        hipLaunchKernelGGL(pmx_flatten_f32_kernel, dim3((unsigned)blocks, (unsigned)m), dim3(256), 0, st, a, dst_dev);
+    }
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}

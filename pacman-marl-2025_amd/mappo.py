@@ -705,6 +705,8 @@ class PPOLearner:
         self.world_size = world_size
         self.autocast_dtype = autocast_dtype
         self._w16 = None
+        self._sh16 = None
+        self._shadow_views = None
 
     def enable_bf16_flat(self):
         """Manual mixed precision instead of autocast for the optimizer step: the network runs on ONE flat bfloat16 copy of
@@ -734,10 +736,31 @@ class PPOLearner:
         if self._w16 is None:
             # one gathering copy instead of loss.backward(): AccumulateGrad ADDS every parameter's gradient into its (zeroed) view
             # of the bucket -- ~80 small kernels per step on this network, a quarter of the launches of the 512-sample step
-            grads = torch.autograd.grad(loss, self.bucket.params, allow_unused=True)
-            flat = [g.reshape(-1) if g is not None else torch.zeros(p.numel(), dtype=self.bucket.grad.dtype, device=self.bucket.grad.device)
+            targets = list(self.bucket.params)
+            if self._shadow_views is not None:
+                for i, v in self._shadow_views.items():
+                    targets[i] = v                           # the bfloat16 copy the library op multiplied by
+            grads = torch.autograd.grad(loss, targets, allow_unused=True)
+            dev = self.bucket.grad.device
+            flat = [g.reshape(-1) if g is not None else torch.zeros(p.numel(), dtype=self.bucket.grad.dtype, device=dev)
                     for g, p in zip(grads, self.bucket.params)]
-            torch.cat(flat, out=self.bucket.grad)
+            if dev.type == "cuda" and all(g.dtype in (torch.float32, torch.bfloat16) for g in flat):
+                import ctypes as C
+                from . import _lib
+                lib = _lib.load()
+                n = len(flat)
+                flat = [g.contiguous() for g in flat]
+                src = (C.c_void_p * n)(*[g.data_ptr() for g in flat])
+                isb = (C.c_uint8 * n)(*[1 if g.dtype == torch.bfloat16 else 0 for g in flat])
+                cnt = (C.c_int32 * n)(*[g.numel() for g in flat])
+                offs, o = [], 0
+                for g in flat:
+                    offs.append(o); o += g.numel()
+                off = (C.c_int64 * n)(*offs)
+                st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                _lib.check(lib.pmx_flatten_to_f32(n, src, isb, off, cnt, self.bucket.grad.data_ptr(), st), "pmx_flatten_to_f32")
+            else:
+                torch.cat([g.to(self.bucket.grad.dtype) for g in flat], out=self.bucket.grad)
             return
         (g16,) = torch.autograd.grad(loss, (self._w16,))
         self.bucket.grad.copy_(g16)
@@ -746,6 +769,39 @@ class PPOLearner:
         if self._w16 is not None:
             with torch.no_grad():
                 self._w16.copy_(self.bucket.data)
+        if self._sh16 is not None:
+            with torch.no_grad():
+                self._sh16.copy_(self.bucket.data)
+
+    # parameters that only torch library ops read (the two heads' linears, the critic's projector): under bf16 autocast each of them
+    # was cast to bfloat16 on use and its gradient cast back -- ~20 small kernels per step.  They are read from a bfloat16 copy of
+    # the WHOLE bucket instead (one cast kernel after the optimizer step); the copy's slices take the parameters' places for the
+    # forward pass and receive the gradients, which pmx_flatten_to_f32 widens into the bucket.  Same roundings as autocast's.
+    SHADOWED = ("actor_head.0.", "actor_head.3.", "critic_projector.0.", "critic_head.0.", "critic_head.2.")
+    shadow_weights = True
+
+    def _shadow_context(self):
+        """Context manager under which the module's library-op parameters are their bfloat16 shadows (and a no-op when the
+        shadows do not apply: CPU, float32 steps, the flat-bf16 mode)."""
+        import contextlib
+        if not (self.shadow_weights and self.autocast_dtype == torch.bfloat16 and self._w16 is None and self.bucket.data.is_cuda):
+            self._shadow_views = None
+            return contextlib.nullcontext()
+        if self._sh16 is None:
+            self._sh16 = self.bucket.data.to(torch.bfloat16).requires_grad_(True)
+            names = [n for n, p in self.model.named_parameters() if p.requires_grad]
+            self._shadow_slots, off = [], 0
+            for i, (n, p) in enumerate(zip(names, self.bucket.params)):
+                if n.startswith(self.SHADOWED):
+                    self._shadow_slots.append((i, n, off, p.numel(), tuple(p.shape)))
+                off += p.numel()
+        self._shadow_views, pd = {}, {}
+        for i, n, off, k, shape in self._shadow_slots:
+            v = self._sh16[off:off + k].view(shape)
+            self._shadow_views[i] = v
+            pd[n] = v
+        from torch.nn.utils import stateless
+        return stateless._reparametrize_module(self.model, pd)
 
     def set_lr(self, lr):
         self.lr = lr
@@ -796,9 +852,10 @@ class PPOLearner:
         if self._w16 is not None:
             loss, stats = self._loss_bf16_flat(obs, merged, act, old_logp, adv, ret, clip_eps, ent_coef)
         elif self.autocast_dtype is not None:
-            with torch.autocast(device_type=dev_type, dtype=self.autocast_dtype):
+            with self._shadow_context(), torch.autocast(device_type=dev_type, dtype=self.autocast_dtype):
                 loss, stats = ppo_loss(self.model, obs, merged, act, old_logp, adv, ret, clip_eps, ent_coef)
         else:
+            self._shadow_views = None
             loss, stats = ppo_loss(self.model, obs, merged, act, old_logp, adv, ret, clip_eps, ent_coef)
         self._backward_into_bucket(loss)
         if self.world_size > 1:
@@ -855,10 +912,11 @@ class PPOLearner:
                 loss, stats = self._loss_bf16_flat(i["obs"], i["merged"], i["act"], i["logp"], i["adv"], i["ret"],
                                                    self._g_sc[2], self._g_sc[3])
             elif self.autocast_dtype is not None:
-                with torch.autocast(device_type=dev.type, dtype=self.autocast_dtype):
+                with self._shadow_context(), torch.autocast(device_type=dev.type, dtype=self.autocast_dtype):
                     loss, stats = ppo_loss(self.model, i["obs"], i["merged"], i["act"], i["logp"], i["adv"], i["ret"],
                                            self._g_sc[2], self._g_sc[3])
             else:
+                self._shadow_views = None
                 loss, stats = ppo_loss(self.model, i["obs"], i["merged"], i["act"], i["logp"], i["adv"], i["ret"],
                                        self._g_sc[2], self._g_sc[3])
             self._backward_into_bucket(loss)

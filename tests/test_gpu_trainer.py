@@ -676,3 +676,30 @@ def test_fused_clip_adam_ema_matches_the_torch_ops():
     for a, b, name in zip(res[True][:5], res[False][:5], ("param", "exp_avg", "exp_avg_sq", "ema", "clipped grad")):
         assert torch.allclose(a, b, rtol=2e-5, atol=1e-7), (name, float((a - b).abs().max()))
     assert all(abs(x - y) <= 1e-5 * y for x, y in zip(res[True][5], res[False][5]))
+
+
+def test_bf16_shadow_weights_give_the_autocast_step():
+    """The optimizer step with the library-op parameters read from the bfloat16 copy of the bucket (PPOLearner.shadow_weights)
+    against the plain autocast step: autocast rounds the same float32 weights to the same bfloat16 values per use, so the
+    gradient and the updated weights agree up to the order of the tower's atomic adds."""
+    from pmx import mappo
+    H, W, B = 11, 14, 256
+    torch.manual_seed(4)
+    obs = (torch.rand(B, 8, H, W, device="cuda") < 0.2).to(torch.uint8)
+    merged = (torch.rand(B // 2, 8, H, W, device="cuda") < 0.2).to(torch.uint8)
+    act = torch.randint(0, 5, (B,), device="cuda")
+    old_logp, adv, ret = -torch.rand(B, device="cuda") - 1, torch.randn(B, device="cuda"), torch.randn(B, device="cuda")
+    res = {}
+    for shadow in (True, False):
+        torch.manual_seed(9)
+        m = mappo.MAPPOAgent((8, H, W)).cuda()
+        L = mappo.PPOLearner(m, autocast_dtype=torch.bfloat16)
+        L.shadow_weights = shadow
+        for _ in range(3):
+            st = L.update_minibatch(obs, merged, act, old_logp, adv, ret)
+        assert (L._sh16 is not None) == shadow
+        res[shadow] = (L.bucket.grad.clone(), L.bucket.data.clone(), float(st["loss"]))
+    g_rel = float((res[True][0] - res[False][0]).norm() / res[False][0].norm())
+    p_rel = float((res[True][1] - res[False][1]).norm() / res[False][1].norm())
+    assert g_rel <= 2e-2 and p_rel <= 1e-4, (g_rel, p_rel)
+    assert abs(res[True][2] - res[False][2]) <= 2e-2 * (abs(res[False][2]) + 1e-2)
