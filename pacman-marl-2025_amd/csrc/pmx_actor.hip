@@ -390,6 +390,195 @@ __global__ __launch_bounds__(256, 2) void pmx_actor_fwd_kernel(const IN_T *__res
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Forward for SMALL batches: one BLOCK (four waves) per sample, each wave owning a contiguous quarter of the position tiles.
+// With one wave per sample a 1 024-sample minibatch is 1 024 waves on 1 024 SIMDs, each walking its sample's 8 layers alone for
+// ~100 us -- a third of the reference-size (512-sample) optimizer step.  Split four ways a sample's layer is: every wave
+// convolves ITS tiles from the block's shared LDS map and leaves its partial GroupNorm sums in LDS; barrier (all reads of the
+// map done, all partial sums there); every wave normalises / activates its tiles and writes them back; barrier.  Same arithmetic
+// per element as pmx_actor_fwd_kernel (the statistics are summed in another order), same dumps for the backward kernels.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename IN_T>
+__device__ __forceinline__ void load_obs_block(const IN_T *__restrict__ obs, char *map, const Geom &G, int tid, int nthreads)
+{
+    for (int i = tid; i < G.HW; i += nthreads) {
+        const int row = i / G.W, col = i - row * G.W;
+        const int pos = (row + 1) * G.WP + col + 1 + GUARD;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = in_to_f<IN_T>(obs[c * G.HW + i]);
+        uint4 w = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+        *reinterpret_cast<uint4 *>(map + map_off(pos, 0)) = w;
+        const uint4 z = {0, 0, 0, 0};
+#pragma unroll
+        for (int ch = 1; ch < 4; ++ch) *reinterpret_cast<uint4 *>(map + map_off(pos, ch)) = z;
+    }
+}
+
+template <int NT, typename IN_T, bool SAVE, int WS>
+__global__ __launch_bounds__(256, 2) void pmx_actor_fwd_split_kernel(const IN_T *__restrict__ obs, const char *__restrict__ pack,
+                                                                    uint2 *__restrict__ feat, uint2 *__restrict__ hsave,
+                                                                    uint2 *__restrict__ ysave, float *__restrict__ stats,
+                                                                    uint2 *__restrict__ rtmp, int B, int H, int W, float eps)
+{
+    constexpr int NTW = (NT + WS - 1) / WS;                    // tiles per wave; WS waves per sample, 4 / WS samples per block
+    constexpr int SPB = 4 / WS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = lane & 15, g = lane >> 4;
+    Geom G;
+    G.H = H, G.W = W, G.WP = W + 2, G.HW = H * W, G.MP = map_positions(NT, W + 2);
+    const int sub = __builtin_amdgcn_readfirstlane(wave / WS), wq = __builtin_amdgcn_readfirstlane(wave % WS);
+    char *map = smem + (size_t)sub * G.MP * 64;
+    float *xs = reinterpret_cast<float *>(smem + (size_t)SPB * G.MP * 64) + sub * (WS * 8);   // [WS waves][4 groups][sum, sum of squares]
+    for (int i = threadIdx.x; i < SPB * G.MP * 4; i += 256) reinterpret_cast<uint4 *>(smem)[i] = uint4{0, 0, 0, 0};
+    const int t0 = __builtin_amdgcn_readfirstlane(wq * NTW);
+    const int tid_s = threadIdx.x - sub * (WS * 64);           // thread index within the sample's waves
+    uint32_t vmask = 0;                                         // which of the lane's positions in the wave's tiles are board cells
+#pragma unroll
+    for (int tl = 0; tl < NTW; ++tl) {
+        const int q = G.WP + 16 * (t0 + tl) + p, row = q / G.WP, col = q - row * G.WP;
+        if (t0 + tl < NT && col >= 1 && col <= W && row <= H) vmask |= 1u << tl;
+    }
+    const short *fw = reinterpret_cast<const short *>(pack + PACK_FWD);
+    const float *biasp = reinterpret_cast<const float *>(pack + PACK_BIAS);
+    const float *gnwp = reinterpret_cast<const float *>(pack + PACK_GNW);
+    const float *gnbp = reinterpret_cast<const float *>(pack + PACK_GNB);
+    const float inv_n = 1.0f / (float)(8 * G.HW);
+
+    for (int s0 = blockIdx.x * SPB; s0 < B; s0 += gridDim.x * SPB) {
+        // a block's samples walk the layers in lock-step (block-wide barriers); a slot past the end of the batch re-does the
+        // last sample (same values to the same addresses: harmless)
+        const int s = s0 + sub < B ? s0 + sub : B - 1;
+        __syncthreads();                                        // the previous sample's last layer has been written and read
+        load_obs_block<IN_T>(obs + (size_t)s * 8 * G.HW, map, G, tid_s, WS * 64);
+        __syncthreads();
+        const short *fws = fw;
+        asm volatile("" : "+s"(fws));
+        bf16x8 A[2][9];
+        load_frags(A, fws, lane);
+#pragma unroll 1
+        for (int li = 0; li < NLAYER; ++li) {
+            int l = li;
+            asm volatile("" : "+s"(l));
+            const bool has_gn = l >= 2;
+            const bool res_on = l >= 3 && (l & 1);
+            int WPv = G.WP, pq = p + GUARD;
+            uint32_t vmk = vmask;
+            asm volatile("" : "+s"(WPv));
+            asm volatile("" : "+v"(pq), "+v"(vmk));
+            uint2 *ydst = SAVE ? ysave + dump_index((size_t)l * B + s, NT, 0, 0, lane) : rtmp + dump_index((size_t)blockIdx.x * SPB + sub, NT, 0, 0, lane);
+            const uint2 *rsrc = SAVE ? ysave + dump_index((size_t)(l >= 2 ? l - 2 : 0) * B + s, NT, 0, 0, lane) : ydst;
+            const bool write_y = SAVE || (l & 1);
+            float bias[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bias[m][r] = biasp[l * 32 + 16 * m + 4 * g + r];
+            uint2 hp[NTW][2];
+            float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+            const char *rbase = map + pq * 64 + g * 16;
+            char *wbase = map + pq * 64 + g * 8;
+#pragma unroll
+            for (int tl = 0; tl < NTW; ++tl) {
+                const int t = t0 + tl;
+                hp[tl][0] = hp[tl][1] = uint2{0u, 0u};
+                if (t < NT) {                                   // wave-uniform
+                    f32x4 a[2];
+                    conv_tile(rbase, A, (WPv + 16 * t) * 64, WPv * 64, a[0], a[1]);
+                    const float vm = ((vmk >> tl) & 1) ? 1.0f : 0.0f;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = (a[m][r] + bias[m][r]) * vm;
+                        uint2 h2 = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+                        asm volatile("" : "+v"(h2.x), "+v"(h2.y));
+                        hp[tl][m] = h2;
+                        const float h0 = lo_f(h2.x), h1 = hi_f(h2.x), h2f = lo_f(h2.y), h3 = hi_f(h2.y);
+                        s1[m] += (h0 + h1) + (h2f + h3);
+                        s2[m] += fmaf(h0, h0, h1 * h1) + fmaf(h2f, h2f, h3 * h3);
+                        if (SAVE) hsave[dump_index((size_t)l * B + s, NT, t, m, lane)] = h2;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // the wave's partial sums of the four GroupNorm groups (group 2m + (g >> 1)) -> LDS
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const float a1 = group_sum(s1[m]), a2 = group_sum(s2[m]);
+                if (p == 0 && (g & 1) == 0) {
+                    xs[(wq * 4 + 2 * m + (g >> 1)) * 2] = a1;
+                    xs[(wq * 4 + 2 * m + (g >> 1)) * 2 + 1] = a2;
+                }
+            }
+            // global loads of pass 2 and of the next layer, in flight across the barrier
+            load_frags(A, fws + (size_t)(l + 1 < NLAYER ? l + 1 : l) * FRAG_PER_LAYER, lane);
+            float gw[2][4], gb[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gw[m][r] = gnwp[l * 32 + 16 * m + 4 * g + r], gb[m][r] = gnbp[l * 32 + 16 * m + 4 * g + r];
+            uint2 rres[NTW][2];
+#pragma unroll
+            for (int tl = 0; tl < NTW; ++tl) {
+                rres[tl][0] = rres[tl][1] = uint2{0u, 0u};
+                if (res_on && t0 + tl < NT) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) rres[tl][m] = rsrc[((t0 + tl) * 2 + m) * 64];
+                }
+            }
+            __syncthreads();                                    // every wave has read the map and left its sums
+            float mean[2], rstd[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int grp = 2 * m + (g >> 1);
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WS; ++w) { a1 += xs[(w * 4 + grp) * 2]; a2 += xs[(w * 4 + grp) * 2 + 1]; }
+                a1 *= inv_n; a2 *= inv_n;
+                mean[m] = has_gn ? a1 : 0.0f;
+                rstd[m] = has_gn ? __builtin_amdgcn_rsqf(fmaxf(a2 - a1 * a1, 0.0f) + eps) : 1.0f;
+            }
+            if (SAVE && wq == 0 && p == 0 && (g & 1) == 0) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    float *st = stats + (((size_t)l * B + s) * 4 + 2 * m + (g >> 1)) * 2;
+                    st[0] = mean[m], st[1] = rstd[m];
+                }
+            }
+#pragma unroll
+            for (int tl = 0; tl < NTW; ++tl) {
+                const int t = t0 + tl;
+                if (t < NT) {
+                    const float vm = ((vmk >> tl) & 1) ? 1.0f : 0.0f;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const float hv[4] = {lo_f(hp[tl][m].x), hi_f(hp[tl][m].x), lo_f(hp[tl][m].y), hi_f(hp[tl][m].y)};
+                        const uint32_t rx = rres[tl][m].x, ry = rres[tl][m].y;
+                        const float rv[4] = {lo_f(rx), hi_f(rx), lo_f(ry), hi_f(ry)};
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float z = rv[r] + fmaf((hv[r] - mean[m]) * rstd[m], gw[m][r], gb[m][r]);
+                            v[r] = gelu_fast(z) * vm;
+                        }
+                        const uint2 y2 = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+                        *reinterpret_cast<uint2 *>(wbase + (WPv + 16 * t) * 64 + m * 32) = y2;
+                        if (write_y) ydst[(t * 2 + m) * 64] = y2;
+                        if (l == NLAYER - 1 && vm != 0.0f) {
+                            const int q = WPv + 16 * t + p, row = q / WPv, col = q - row * WPv;
+                            feat[((size_t)s * G.HW + (row - 1) * W + (col - 1)) * 8 + 4 * m + g] = y2;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            __syncthreads();                                    // the layer's output is complete in the map (and xs may be rewritten)
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Backward, data path: one wave owns a sample from the last layer back to the first, mirroring the forward kernel.  The
 // gradient travels from layer to layer in REGISTERS (P layout, packed bf16 -- the rounding autograd applies to a bf16
 // tensor), the skip-connection gradient of a block as well; per layer the kernel reads the saved pre-activation (and the
@@ -925,6 +1114,23 @@ int grid_for(int64_t B, int blocks_per_cu)
     return (int)(want < cap ? want : cap);
 }
 
+// batches up to this size take the four-waves-per-sample kernels (PMX_ACTOR_SPLIT_MAX overrides, 0 = never; read once)
+int64_t split_max_batch()
+{
+    static const int64_t v = [] { const char *e = getenv("PMX_ACTOR_SPLIT_MAX"); return e ? (int64_t)atoll(e) : (int64_t)1536; }();
+    return v;
+}
+
+// waves per sample of the small-batch forward kernel: four while every sample's block is resident at once (two blocks of ~190
+// registers per CU: 512 samples), two beyond (measured at 1 024 samples: one wave per sample 112 us, two 85 us, four 103 us -- at
+// four the blocks no longer fit in one round).  PMX_ACTOR_SPLIT_WAVES = 2 / 4 forces one (read once).
+int split_waves(int64_t B)
+{
+    static const int forced = [] { const char *e = getenv("PMX_ACTOR_SPLIT_WAVES"); return e ? atoi(e) : 0; }();
+    if (forced == 2 || forced == 4) return forced;
+    return B <= 512 ? 4 : 2;
+}
+
 template <int NT, typename IN_T>
 int launch_fwd(const void *obs, const void *pack, void *feat, void *save, void *scratch, int64_t B, int H, int W, hipStream_t st)
 {
@@ -934,6 +1140,26 @@ int launch_fwd(const void *obs, const void *pack, void *feat, void *save, void *
     float *stt = hs ? reinterpret_cast<float *>(ys + 8 * B * dump) : nullptr;
     uint2 *rtmp = reinterpret_cast<uint2 *>(scratch);
     if (!save && !rtmp) return PMX_ERR_INVALID;
+    if (B <= split_max_batch()) {
+        // small batch: several waves per sample (pmx_actor_fwd_split_kernel); 2 048 skip slots exist in the scratch area
+        const int ws = split_waves(B);
+        const int spb = 4 / ws;
+        const size_t lds_s = (size_t)spb * map_positions(NT, W + 2) * 64 + (size_t)spb * ws * 8 * sizeof(float);
+        int64_t g64 = (B + spb - 1) / spb;
+        if (g64 * spb > 2048) g64 = 2048 / spb;
+        const unsigned grid = (unsigned)g64;
+#define PMX_FWD_SPLIT(SAVEV, WSV)                                                                                           \
+    do {                                                                                                                    \
+        int rc = allow_lds(pmx_actor_fwd_split_kernel<NT, IN_T, SAVEV, WSV>, lds_s);                                        \
+        if (rc) return rc;                                                                                                  \
+        hipLaunchKernelGGL((pmx_actor_fwd_split_kernel<NT, IN_T, SAVEV, WSV>), dim3(grid), dim3(256), lds_s, st, (const IN_T *)obs, \
+                           (const char *)pack, (uint2 *)feat, hs, ys, stt, rtmp, (int)B, H, W, 1e-5f);                       \
+    } while (0)
+        if (save) { if (ws == 2) PMX_FWD_SPLIT(true, 2); else PMX_FWD_SPLIT(true, 4); }
+        else { if (ws == 2) PMX_FWD_SPLIT(false, 2); else PMX_FWD_SPLIT(false, 4); }
+#undef PMX_FWD_SPLIT
+        return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+    }
     if (save) {
         int rc = allow_lds(pmx_actor_fwd_kernel<NT, IN_T, true>, lds);
         if (rc) return rc;
