@@ -57,6 +57,7 @@ constexpr int GRAD_B = GRAD_W + NLAYER * 36 * 256;
 constexpr int GRAD_GNW = GRAD_B + NLAYER * 32;
 constexpr int GRAD_GNB = GRAD_GNW + NLAYER * 32;
 constexpr int GRAD_FLOATS = GRAD_GNB + NLAYER * 32;
+constexpr int W_PART_ROWS = 128;               // most sample chunks (partial rows) of the weight-gradient kernel
 static_assert(GRAD_FLOATS == PMX_ACTOR_GRAD_FLOATS, "include/pmx.h and pmx_actor.hip disagree on the gradient size");
 
 __host__ __device__ constexpr int map_positions(int nt, int wp) { return GUARD + wp + 32 * ((nt + 1) / 2) + wp + 3; }
@@ -874,13 +875,32 @@ __global__ __launch_bounds__(256) void pmx_actor_sum_acc_kernel(const float *__r
     }
 }
 
+// weight gradients: sum of the weight-gradient kernel's per-chunk rows ([n_rows][NLAYER * 36 * 256]) into the gradient buffer
+__global__ __launch_bounds__(256) void pmx_actor_sum_w_kernel(const float *__restrict__ wpart, int n_rows, float *__restrict__ grad)
+{
+    __shared__ float part[8][33];
+    const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + c;                               // NLAYER * 36 * 256 = 73 728 columns: 2 304 blocks
+    constexpr size_t ROW = (size_t)NLAYER * 36 * 256;
+    float acc = 0.f;
+    for (int r = sl; r < n_rows; r += 8) acc += wpart[(size_t)r * ROW + i];
+    part[sl][c] = acc;
+    __syncthreads();
+    if (sl == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += part[k][c];
+        grad[GRAD_W + i] = t;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Backward, weight gradient: dW[co][ci][tap] = sum over samples and positions of dH[pos][co] X[pos + shift(tap)][ci], a
 // contraction over POSITIONS.  blockIdx.y = layer, blockIdx.x = chunk of samples; a wave keeps the layer's 36 output tiles
 // (2 co-halves x 2 ci-halves x 9 taps, 144 accumulator registers) across its samples.  Per sample: the A operands
 // (dH, already in operand layout) come straight from global memory, the layer's input activation goes into the wave's LDS
 // map once and is read back tap by tap through the transposing read.  One block-level sum through LDS and one float
-// atomic per value at the end.
+// plain store per value at the end (the chunk's partial row; pmx_actor_sum_w_kernel adds the rows).
 // ---------------------------------------------------------------------------------------------------------------
 template <int NT, typename IN_T>
 __global__ __launch_bounds__(256, 2) void pmx_actor_bwd_weight_kernel(const IN_T *__restrict__ obs, const uint2 *__restrict__ ysave,
@@ -943,7 +963,7 @@ __global__ __launch_bounds__(256, 2) void pmx_actor_bwd_weight_kernel(const IN_T
                 }
         }
     }
-    // block-level sum through LDS (the maps are free now), then one atomic add per value
+    // block-level sum through LDS (the maps are free now), then the block's partial row of the weight gradient
     __syncthreads();
     float *red = reinterpret_cast<float *>(smem);
     constexpr int PER_ROUND = 9;                              // 4 waves x 9 tiles x 1 KB = 36 KB of scratch per round
@@ -960,11 +980,10 @@ __global__ __launch_bounds__(256, 2) void pmx_actor_bwd_weight_kernel(const IN_T
                 const f32x4 u = *reinterpret_cast<const f32x4 *>(red + ((size_t)w * PER_ROUND * 64 + i) * 4);
                 v[0] += u[0], v[1] += u[1], v[2] += u[2], v[3] += u[3];
             }
-            float *dst = grad + GRAD_W + ((size_t)l * 36 + round * PER_ROUND) * 256 + (size_t)i * 4;
-            if (v[0] != 0.f) atomicAdd(dst + 0, v[0]);
-            if (v[1] != 0.f) atomicAdd(dst + 1, v[1]);
-            if (v[2] != 0.f) atomicAdd(dst + 2, v[2]);
-            if (v[3] != 0.f) atomicAdd(dst + 3, v[3]);
+            // the block's partial row (plain stores; pmx_actor_sum_w_kernel adds the rows): 64 blocks adding 9 216 values each
+            // with float atomics onto the same addresses cost more than the row sum, at small batches most of the kernel
+            float *dst = grad + ((size_t)blockIdx.x * NLAYER * 36 + (size_t)l * 36 + round * PER_ROUND) * 256 + (size_t)i * 4;
+            *reinterpret_cast<f32x4 *>(dst) = v;
         }
         __syncthreads();
     }
@@ -1053,7 +1072,8 @@ extern "C" int pmx_actor_sizes(int32_t H, int32_t W, int64_t B, int64_t *save_by
     if (save_bytes) *save_bytes = B * (8 * dump + 8 * dump + 8 * 4 * 2 * 4);
     if (scratch_bytes) {
         const int64_t infer = 2048 * dump;                                     // inference: one skip-input slot per resident wave
-        const int64_t bwd = B * 8 * (int64_t)((tiles_for(H, W) + 1) / 2) * 2048 + infer + 1024 * 768 * 4; // backward: dH operand fragments of the 8 layers + skip slots + partial sums
+        const int64_t bwd = B * 8 * (int64_t)((tiles_for(H, W) + 1) / 2) * 2048 + infer + 1024 * 768 * 4 +
+                            (int64_t)W_PART_ROWS * NLAYER * 36 * 256 * 4;   // backward: dH operand fragments of the 8 layers + skip slots + the two kernels' partial rows
         *scratch_bytes = infer > bwd ? infer : bwd;
     }
     return PMX_OK;
@@ -1200,13 +1220,16 @@ int launch_bwd(const void *obs, const void *pack, const void *save, const void *
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     int64_t chunks = (2 * cus) / NLAYER;
+    if (chunks > W_PART_ROWS) chunks = W_PART_ROWS;
     int64_t per_wave = (B + chunks * 4 - 1) / (chunks * 4);
     if (per_wave < 2) per_wave = 2;
     chunks = (B + per_wave * 4 - 1) / (per_wave * 4);
     rc = allow_lds(pmx_actor_bwd_weight_kernel<NT, IN_T>, lds_w);
     if (rc) return rc;
+    float *wpart = accpart + (size_t)1024 * 768;                             // then the weight kernel's per-chunk rows
     hipLaunchKernelGGL((pmx_actor_bwd_weight_kernel<NT, IN_T>), dim3((unsigned)chunks, NLAYER), dim3(256), lds_w, st, (const IN_T *)obs, ys,
-                       (const bf16x8 *)da, grad, (int)B, H, W, (int)per_wave);
+                       (const bf16x8 *)da, wpart, (int)B, H, W, (int)per_wave);
+    hipLaunchKernelGGL(pmx_actor_sum_w_kernel, dim3(NLAYER * 36 * 256 / 32), dim3(256), 0, st, (const float *)wpart, (int)chunks, grad);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
 
@@ -1243,8 +1266,8 @@ extern "C" int pmx_actor_backward(const void *obs_dev, int32_t obs_dtype, const 
     if (!obs_dev || !pack_dev || !save_dev || !dfeat_dev || !scratch_dev || !grad_dev || B < 0) return PMX_ERR_INVALID;
     if (!pmx_actor_supported(H, W)) return PMX_ERR_UNSUPPORTED;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(grad_dev, 0, sizeof(float) * GRAD_FLOATS, st) != hipSuccess) return PMX_ERR_HIP;
-    if (B == 0) return PMX_OK;
+    if (B == 0) return hipMemsetAsync(grad_dev, 0, sizeof(float) * GRAD_FLOATS, st) == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+    // (no memset otherwise: the two row-sum kernels write every word of the gradient)
     const int nt = tiles_for(H, W);
 #ifdef PMX_ACTOR_EXP
 #define PMX_BWD(NT) return launch_bwd<11, __hip_bfloat16>(obs_dev, pack_dev, save_dev, dfeat_dev, scratch_dev, grad_dev, B, H, W, st);
