@@ -849,6 +849,274 @@ __global__ __launch_bounds__(256, 1) void pmx_actor_bwd_data_kernel(const char *
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The data path for SMALL batches, WS = 2 or 4 waves per sample (the counterpart of pmx_actor_fwd_split_kernel): a wave owns a
+// contiguous share of the position tiles -- its slice of dY / dz, of the saved pre-activation and of the skip data -- and the
+// sample's waves share one LDS map.  Per layer: pass 1 on the own tiles, partial GroupNorm-backward sums to LDS, BARRIER (sums
+// complete; nobody still reads the map for the previous layer's input gradient), pass 2 writes dH for the own tiles, BARRIER
+// (map complete), then the transposed dumps (key-pair blocks dealt round-robin) and the input-gradient convolution of the own
+// tiles.  At 512 samples the one-wave kernel is 512 waves walking 8 layers alone (118 us); registers are no concern here (one
+// wave per SIMD either way), the point is the length of a sample's serial chain.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT, int WS>
+__global__ __launch_bounds__(256, WS == 4 ? 2 : 1) void pmx_actor_bwd_data_split_kernel(const char *__restrict__ pack, const uint2 *__restrict__ dfeat,
+                                                                         const uint2 *__restrict__ hsave, const uint2 *__restrict__ ysave,
+                                                                         const float *__restrict__ stats, bf16x8 *__restrict__ dasave,
+                                                                         uint2 *__restrict__ sktmp, float *__restrict__ accpart, int B,
+                                                                         int H, int W)
+{
+    constexpr int NTW = (NT + WS - 1) / WS, SPB = 4 / WS, KS = (NT + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = lane & 15, g = lane >> 4;
+    Geom G;
+    G.H = H, G.W = W, G.WP = W + 2, G.HW = H * W, G.MP = map_positions(NT, W + 2);
+    const int sub = __builtin_amdgcn_readfirstlane(wave / WS), wq = __builtin_amdgcn_readfirstlane(wave % WS);
+    // LDS: [SPB maps][4 per-wave accumulators of NLAYER * 96 floats][SPB x WS x 8 floats of partial sums]
+    char *map = smem + (size_t)sub * G.MP * 64;
+    float *acc = reinterpret_cast<float *>(smem + (size_t)SPB * G.MP * 64) + wave * (NLAYER * 96);
+    float *xs = reinterpret_cast<float *>(smem + (size_t)SPB * G.MP * 64) + 4 * (NLAYER * 96) + sub * (WS * 8);
+    for (int i = threadIdx.x; i < SPB * G.MP * 4; i += 256) reinterpret_cast<uint4 *>(smem)[i] = uint4{0, 0, 0, 0};
+    for (int i = lane; i < NLAYER * 96; i += 64) acc[i] = 0.0f;
+    const int t0 = __builtin_amdgcn_readfirstlane(wq * NTW);
+    uint32_t vmask = 0;
+#pragma unroll
+    for (int tl = 0; tl < NTW; ++tl) {
+        const int q = G.WP + 16 * (t0 + tl) + p, row = q / G.WP, col = q - row * G.WP;
+        if (t0 + tl < NT && col >= 1 && col <= W && row <= H) vmask |= 1u << tl;
+    }
+    const short *bw = reinterpret_cast<const short *>(pack + PACK_BWD);
+    const float *gnwp = reinterpret_cast<const float *>(pack + PACK_GNW);
+    const float *gnbp = reinterpret_cast<const float *>(pack + PACK_GNB);
+    const float inv_n = 1.0f / (float)(8 * G.HW);
+    const int tr_row = (lane & 15) >> 2, tr_pc = lane & 3;
+
+    for (int s0 = blockIdx.x * SPB; s0 < B; s0 += gridDim.x * SPB) {
+        // a block's samples walk the layers in lock-step; a slot past the end of the batch re-does the last sample (its dumps
+        // are the same values to the same addresses) but adds nothing to the parameter gradients
+        const bool live = s0 + sub < B;
+        const int s = live ? s0 + sub : B - 1;
+        uint2 dv[NTW][2];
+        uint2 *skp = sktmp + dump_index((size_t)blockIdx.x * SPB + sub, NT, 0, 0, lane);
+        {
+            int WPo = G.WP;
+            asm volatile("" : "+s"(WPo));
+#pragma unroll
+            for (int tl = 0; tl < NTW; ++tl) {
+                const int q = WPo + 16 * (t0 + tl) + p, row = q / WPo, col = q - row * WPo;
+                const bool valid = (vmask >> tl) & 1;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    dv[tl][m] = uint2{0, 0};
+                    if (valid) dv[tl][m] = dfeat[((size_t)s * G.HW + (row - 1) * W + (col - 1)) * 8 + 4 * m + g];
+                }
+            }
+        }
+        uint2 hp[NTW][2], xg[NTW][2];
+        float gw[2][4], gb[2][4], mean[2], rstd[2];
+        auto load_layer_inputs = [&](int ln) {
+            const bool res_n = ln >= 3 && (ln & 1);
+            const int lres = ln >= 2 ? ln - 2 : 0;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gw[m][r] = gnwp[ln * 32 + 16 * m + 4 * g + r], gb[m][r] = gnbp[ln * 32 + 16 * m + 4 * g + r];
+                const float *st = stats + (((size_t)ln * B + s) * 4 + 2 * m + (g >> 1)) * 2;
+                mean[m] = st[0], rstd[m] = st[1];
+            }
+#pragma unroll
+            for (int tl = 0; tl < NTW; ++tl)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    hp[tl][m] = xg[tl][m] = uint2{0u, 0u};
+                    if (t0 + tl < NT) {
+                        hp[tl][m] = hsave[dump_index((size_t)ln * B + s, NT, t0 + tl, m, lane)];
+                        if (res_n) xg[tl][m] = ysave[dump_index((size_t)lres * B + s, NT, t0 + tl, m, lane)];
+                    }
+                }
+        };
+        load_layer_inputs(NLAYER - 1);
+#pragma unroll 1
+        for (int li = NLAYER - 1; li >= 0; --li) {
+            int l = __builtin_amdgcn_readfirstlane(li);
+            asm volatile("" : "+s"(l));
+            const bool has_gn = l >= 2, has_res = l >= 3 && (l & 1), adds_skip = l >= 2 && !(l & 1);
+            const float gn_on = has_gn ? 1.0f : 0.0f;
+            int WPv = G.WP, pq = p + GUARD;
+            uint32_t vmk = vmask;
+            asm volatile("" : "+s"(WPv));
+            asm volatile("" : "+v"(pq), "+v"(vmk));
+            // ---- pass 1 on the own tiles ---------------------------------------------------------------------------------
+            float S1[2] = {0.f, 0.f}, S2[2] = {0.f, 0.f};
+            float dgw[2][4], dgb[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dgw[m][r] = dgb[m][r] = 0.0f;
+#pragma unroll
+            for (int tl = 0; tl < NTW; ++tl) {
+                if (t0 + tl < NT) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const uint2 dy = dv[tl][m], h2 = hp[tl][m], x2 = xg[tl][m];
+                        const float hv[4] = {lo_f(h2.x), hi_f(h2.x), lo_f(h2.y), hi_f(h2.y)};
+                        const float xv[4] = {lo_f(x2.x), hi_f(x2.x), lo_f(x2.y), hi_f(x2.y)};
+                        const float d[4] = {lo_f(dy.x), hi_f(dy.x), lo_f(dy.y), hi_f(dy.y)};
+                        float dzf[4], xh[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            xh[r] = (hv[r] - mean[m]) * rstd[m];
+                            const float z = xv[r] + fmaf(xh[r], gw[m][r], gb[m][r]);
+                            float e;
+                            const float phi = phi_cdf(z, e);
+                            dzf[r] = d[r] * fmaf(z * 0.3989422804014327f, e, phi);
+                        }
+                        uint2 dzq = {pack2(dzf[0], dzf[1]), pack2(dzf[2], dzf[3])};
+                        asm volatile("" : "+v"(dzq.x), "+v"(dzq.y));
+                        dv[tl][m] = dzq;
+                        const float dzr[4] = {lo_f(dzq.x), hi_f(dzq.x), lo_f(dzq.y), hi_f(dzq.y)};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            dgb[m][r] += dzr[r];
+                            dgw[m][r] = fmaf(dzr[r], xh[r], dgw[m][r]);
+                            const float gd = gw[m][r] * dzr[r];
+                            S1[m] += gd;
+                            S2[m] = fmaf(gd, xh[r], S2[m]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            if (has_res) {
+#pragma unroll
+                for (int tl = 0; tl < NTW; ++tl)
+                    if (t0 + tl < NT) {
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) skp[((t0 + tl) * 2 + m) * 64] = dv[tl][m];
+                    }
+            }
+            // the wave's partial sums of the four groups -> LDS; after the barrier every wave adds all of them
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const float a1 = group_sum(S1[m]), a2 = group_sum(S2[m]);
+                if (p == 0 && (g & 1) == 0) {
+                    xs[(wq * 4 + 2 * m + (g >> 1)) * 2] = a1;
+                    xs[(wq * 4 + 2 * m + (g >> 1)) * 2 + 1] = a2;
+                }
+            }
+            const short *bws = bw + (size_t)l * FRAG_PER_LAYER;
+            asm volatile("" : "+s"(bws));
+            bf16x8 A[2][9];
+            load_frags(A, bws, lane);                           // in flight across the barriers
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int grp = 2 * m + (g >> 1);
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WS; ++w) { a1 += xs[(w * 4 + grp) * 2]; a2 += xs[(w * 4 + grp) * 2 + 1]; }
+                S1[m] = a1 * inv_n * gn_on, S2[m] = a2 * inv_n * gn_on;
+            }
+            // ---- pass 2: dh of the own tiles into the shared map ----------------------------------------------------------
+            float dbias[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dbias[m][r] = 0.0f;
+            char *wbase = map + pq * 64 + g * 8;
+#pragma unroll
+            for (int tl = 0; tl < NTW; ++tl) {
+                const int t = t0 + tl;
+                if (t < NT) {
+                    const float vm = ((vmk >> tl) & 1) ? 1.0f : 0.0f;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const uint2 h2 = hp[tl][m];
+                        const float hv[4] = {lo_f(h2.x), hi_f(h2.x), lo_f(h2.y), hi_f(h2.y)};
+                        const float dzr[4] = {lo_f(dv[tl][m].x), hi_f(dv[tl][m].x), lo_f(dv[tl][m].y), hi_f(dv[tl][m].y)};
+                        float dh[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float xh = (hv[r] - mean[m]) * rstd[m];
+                            dh[r] = vm * rstd[m] * (gw[m][r] * dzr[r] - S1[m] - xh * S2[m]);
+                        }
+                        const uint2 d2 = {pack2(dh[0], dh[1]), pack2(dh[2], dh[3])};
+                        dbias[m][0] += lo_f(d2.x), dbias[m][1] += hi_f(d2.x), dbias[m][2] += lo_f(d2.y), dbias[m][3] += hi_f(d2.y);
+                        *reinterpret_cast<uint2 *>(wbase + (WPv + 16 * t) * 64 + m * 32) = d2;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            uint2 skip[NTW][2];
+#pragma unroll
+            for (int tl = 0; tl < NTW; ++tl) {
+                skip[tl][0] = skip[tl][1] = uint2{0u, 0u};
+                if (adds_skip && t0 + tl < NT) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) skip[tl][m] = skp[((t0 + tl) * 2 + m) * 64];
+                }
+            }
+            load_layer_inputs(l > 0 ? l - 1 : 0);
+            if (live) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float b = pos_sum(dbias[m][r]), w = pos_sum(dgw[m][r]), c = pos_sum(dgb[m][r]);
+                        if (p == 0) {
+                            float *a3 = acc + l * 96 + 16 * m + 4 * g + r;
+                            a3[0] += b, a3[32] += w, a3[64] += c;
+                        }
+                    }
+            }
+            __syncthreads();                                    // the layer's dH is complete in the map
+            // ---- dH in the weight-gradient kernel's operand layout: the key-pair blocks dealt round-robin to the waves -----
+            {
+                bf16x8 *dst = dasave + (((size_t)l * B + s) * KS * 2) * 64 + lane;
+                const char *tbase = map + (8 * g + tr_row + GUARD) * 64 + tr_pc * 8;
+#pragma unroll 1
+                for (int ks = wq; ks < KS; ks += WS) {
+#pragma unroll
+                    for (int mo = 0; mo < 2; ++mo) {
+                        const char *o0 = tbase + (WPv + 32 * ks) * 64 + mo * 32;
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)(o0));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)(o0 + 256));
+                        dst[(ks * 2 + mo) * 64] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
+                }
+            }
+            // ---- input gradient of the own tiles ---------------------------------------------------------------------------
+            if (l > 0) {
+#pragma unroll
+                for (int tl = 0; tl < NTW; ++tl) {
+                    const int t = t0 + tl;
+                    if (t < NT) {
+                        f32x4 a[2];
+                        conv_tile(map + pq * 64 + g * 16, A, (WPv + 16 * t) * 64, WPv * 64, a[0], a[1]);
+                        const float vm = ((vmk >> tl) & 1) ? 1.0f : 0.0f;
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            const uint32_t sx = skip[tl][m].x, sy = skip[tl][m].y;
+                            const float v0 = (lo_f(sx) + a[m][0]) * vm, v1 = (hi_f(sx) + a[m][1]) * vm;
+                            const float v2 = (lo_f(sy) + a[m][2]) * vm, v3 = (hi_f(sy) + a[m][3]) * vm;
+                            uint2 nx = {pack2(v0, v1), pack2(v2, v3)};
+                            asm volatile("" : "+v"(nx.x), "+v"(nx.y));
+                            dv[tl][m] = nx;
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        __syncthreads();                                        // the last layer's map reads are done before the next sample's writes
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NLAYER * 96; i += 256) {
+        const float *a0 = reinterpret_cast<const float *>(smem + (size_t)SPB * G.MP * 64);
+        accpart[(size_t)blockIdx.x * (NLAYER * 96) + i] = (a0[i] + a0[NLAYER * 96 + i]) + (a0[2 * NLAYER * 96 + i] + a0[3 * NLAYER * 96 + i]);
+    }
+}
+
 // bias / GroupNorm-affine gradients: sum of the data kernel's per-block rows into the gradient buffer
 __global__ __launch_bounds__(256) void pmx_actor_sum_acc_kernel(const float *__restrict__ accpart, int n_rows, float *__restrict__ grad)
 {
@@ -1209,9 +1477,31 @@ int launch_bwd(const void *obs, const void *pack, const void *save, const void *
     const size_t lds_d = (size_t)4 * (mp * 64 + NLAYER * 96 * 4);
     int rc = allow_lds(pmx_actor_bwd_data_kernel<NT>, lds_d);
     if (rc) return rc;
-    const int grid_d = grid_for(B, 2);
-    hipLaunchKernelGGL((pmx_actor_bwd_data_kernel<NT>), dim3(grid_d), dim3(256), lds_d, st, (const char *)pack, (const uint2 *)dfeat,
-                       hs, ys, stt, da, sk, accpart, (int)B, H, W);
+    int grid_d = grid_for(B, 2);
+    if (B <= split_max_batch() && B <= 512) {
+        // small batch: four waves per sample (pmx_actor_bwd_data_split_kernel).  Measured: 256 samples 56 us, 512 samples 69 us
+        // against 118 us for one wave per sample; at 1 024 samples the split kernels (two waves 160 us, four 135 us) lose to the
+        // one-wave kernel (121 us): by then every SIMD has a wave and the kernel runs at its large-batch rate per sample
+        const int ws = split_waves(B), spb = 4 / ws;
+        const size_t lds_s = (size_t)spb * mp * 64 + (size_t)4 * NLAYER * 96 * 4 + (size_t)spb * ws * 8 * 4;
+        int64_t g64 = (B + spb - 1) / spb;
+        if (g64 > 1024) g64 = 1024;                          // accpart has 1 024 rows; the skip slots (2 048) cover grid * spb
+        grid_d = (int)g64;
+        if (ws == 2) {
+            rc = allow_lds(pmx_actor_bwd_data_split_kernel<NT, 2>, lds_s);
+            if (rc) return rc;
+            hipLaunchKernelGGL((pmx_actor_bwd_data_split_kernel<NT, 2>), dim3(grid_d), dim3(256), lds_s, st, (const char *)pack,
+                               (const uint2 *)dfeat, hs, ys, stt, da, sk, accpart, (int)B, H, W);
+        } else {
+            rc = allow_lds(pmx_actor_bwd_data_split_kernel<NT, 4>, lds_s);
+            if (rc) return rc;
+            hipLaunchKernelGGL((pmx_actor_bwd_data_split_kernel<NT, 4>), dim3(grid_d), dim3(256), lds_s, st, (const char *)pack,
+                               (const uint2 *)dfeat, hs, ys, stt, da, sk, accpart, (int)B, H, W);
+        }
+    } else {
+        hipLaunchKernelGGL((pmx_actor_bwd_data_kernel<NT>), dim3(grid_d), dim3(256), lds_d, st, (const char *)pack, (const uint2 *)dfeat,
+                           hs, ys, stt, da, sk, accpart, (int)B, H, W);
+    }
     hipLaunchKernelGGL(pmx_actor_sum_acc_kernel, dim3(NLAYER * 96 / 32), dim3(256), 0, st, (const float *)accpart, grid_d, grad);
     if (hipGetLastError() != hipSuccess) return PMX_ERR_HIP;
     // weight gradient: layers x sample chunks; about two blocks per CU in total, each wave at least a few samples
