@@ -1409,6 +1409,12 @@ int64_t split_max_batch()
     return v;
 }
 
+int64_t split_bwd_max_batch()      // the data-gradient kernel splits samples over waves up to this batch (PMX_ACTOR_SPLIT_BWD_MAX, read once)
+{
+    static const int64_t v = [] { const char *e = getenv("PMX_ACTOR_SPLIT_BWD_MAX"); return e ? (int64_t)atoll(e) : (int64_t)512; }();
+    return v;
+}
+
 // waves per sample of the small-batch forward kernel: four while every sample's block is resident at once (two blocks of ~190
 // registers per CU: 512 samples), two beyond (measured at 1 024 samples: one wave per sample 112 us, two 85 us, four 103 us -- at
 // four the blocks no longer fit in one round).  PMX_ACTOR_SPLIT_WAVES = 2 / 4 forces one (read once).
@@ -1478,7 +1484,7 @@ int launch_bwd(const void *obs, const void *pack, const void *save, const void *
     int rc = allow_lds(pmx_actor_bwd_data_kernel<NT>, lds_d);
     if (rc) return rc;
     int grid_d = grid_for(B, 2);
-    if (B <= split_max_batch() && B <= 512) {
+    if (B <= split_max_batch() && B <= split_bwd_max_batch()) {
         // small batch: four waves per sample (pmx_actor_bwd_data_split_kernel).  Measured: 256 samples 56 us, 512 samples 69 us
         // against 118 us for one wave per sample; at 1 024 samples the split kernels (two waves 160 us, four 135 us) lose to the
         // one-wave kernel (121 us): by then every SIMD has a wave and the kernel runs at its large-batch rate per sample
