@@ -14,11 +14,8 @@ timeout -k 10 300 python bench.py --obs bfloat16 --no-ppo > $O/bench_small_bfloa
 timeout -k 10 300 python bench.py --obs uint8 --no-ppo > $O/bench_small_uint8.json 2>/dev/null
 timeout -k 10 300 python bench.py --envs 65536 --no-ppo > $O/bench_small65536.json 2>/dev/null
 echo benches done
+bash tools/tick_prof.sh $O
 cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_tick -- python3 $ROOT/bench.py --steps 300 --warmup 50 --no-cpu-baseline --no-ppo --no-unidirectional --fixed-sweep > /tmp/prof_tick.log 2>&1
-python3 $ROOT/tools/prof_summary.py $(find /tmp/prof_tick -name "*kernel_stats.csv" | head -1) "" 12 > $ROOT/$O/kernel_stats_tick_small16384_f32_fixed_sweep.txt
-cp $(find /tmp/prof_tick -name "*kernel_stats.csv" | head -1) $ROOT/$O/kernel_stats_tick_small16384_f32_fixed_sweep.csv
-tail -1 /tmp/prof_tick.log > $ROOT/$O/bench_line_of_the_profiled_run.json
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_step -- python3 $ROOT/tools/train_bench.py --envs 8192 --horizon 16 --minibatch 16384 --updates 3 > /tmp/prof_step.log 2>&1
 python3 $ROOT/tools/prof_summary.py $(find /tmp/prof_step -name "*kernel_stats.csv" | head -1) "" 60 > $ROOT/$O/kernel_stats_train_step_mb16384.txt
 tail -1 /tmp/prof_step.log > $ROOT/$O/train_bench_of_the_profiled_run.json
