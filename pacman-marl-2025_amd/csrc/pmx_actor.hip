@@ -75,7 +75,6 @@ __device__ __forceinline__ uint32_t pack2(float a, float b)
 }
 __device__ __forceinline__ float lo_f(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float hi_f(uint32_t u) { return __uint_as_float(u & 0xFFFF0000u); }
-__device__ __forceinline__ float bf16_round(float v) { return lo_f(pack2(v, 0.0f)); }
 
 // Phi(z) = 0.5 (1 + erf(z / sqrt 2)) by Abramowitz-Stegun 7.1.26 (|error of erf| <= 1.5e-7) and e = exp(-z^2 / 2).
 // GELU(z) = z Phi(z) (nn.GELU() exact form, pacman_mappo_resnet.py:53), GELU'(z) = Phi(z) + z e / sqrt(2 pi).
@@ -151,12 +150,6 @@ __device__ __forceinline__ void load_obs(const IN_T *__restrict__ obs, char *map
 #pragma unroll
         for (int ch = 1; ch < 4; ++ch) *reinterpret_cast<uint4 *>(map + map_off(pos, ch)) = z;
     }
-}
-
-__device__ __forceinline__ void load_frags_half(bf16x8 (&A)[2][9], const short *__restrict__ frag, int lane, int m)
-{
-#pragma unroll
-    for (int k = 0; k < 9; ++k) A[m][k] = *reinterpret_cast<const bf16x8 *>(frag + ((m * 9 + k) * 64 + lane) * 8);
 }
 
 __device__ __forceinline__ void load_frags(bf16x8 (&A)[2][9], const short *__restrict__ frag, int lane)
@@ -1315,8 +1308,6 @@ __global__ __launch_bounds__(256) void pmx_actor_unpack_kernel(UnpackArgs a, con
 }
 
 int tiles_for(int H, int W) { return (H * (W + 2) + 15) / 16; }
-
-thread_local char g_err[256];
 
 }   // namespace
 
