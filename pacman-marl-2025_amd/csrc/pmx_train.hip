@@ -603,6 +603,7 @@ extern "C" int pmx_gn8_gelu_backward(const void *h, const void *res, const void 
 // ---------------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) short pmx_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float pmx_f32x4;
+typedef __attribute__((ext_vector_type(4))) short pmx_bf16x4;
 
 __device__ __forceinline__ short pmx_f2bf(float f)
 {
@@ -993,6 +994,160 @@ __global__ __launch_bounds__(512) void pmx_attn8_bwd_kernel(const __hip_bfloat16
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same backward with ONE pass and one wavefront per (sample, head), for sequences of exactly NPF pairs of 16-row tiles
+// (160 padded tokens: tinyCapture / smallCapture).  The two-pass kernel computes every probability and every dS twice -- once
+// with keys on the rows for dQ, once with queries on the rows for dK / dV -- and the softmax arithmetic is what bounds it.
+// Here the dK / dV orientation is computed once per (key tile, query pair); its dS tile (queries on the accumulator rows, keys on
+// the lanes) is written to a 32-row LDS staging block as [key][query] and read back through ds_read_b64_tr_b16 as the B operand
+// dS^T[key][query] of dQ^T += K^T . dS^T, whose A operand is 8 consecutive keys of K^T per lane group straight from LDS.  dQ^T of
+// all ten query tiles stays in registers (40) across the key tiles.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NPF>
+__global__ __launch_bounds__(256) void pmx_attn8_bwd_fused_kernel(const __hip_bfloat16 *__restrict__ qkv, const __hip_bfloat16 *__restrict__ outp,
+                                                                  const __hip_bfloat16 *__restrict__ dout, const float *__restrict__ lse,
+                                                                  __hip_bfloat16 *__restrict__ dqkv, int S, int B, float scale, int bm)
+{
+    constexpr int D = 8, HEADS = 4, E = 32, S_pad = 32 * NPF, TROW = 80;       // TROW: bytes per staging row (32 queries + pad)
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int h = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x;
+    constexpr size_t per_wave = (size_t)3 * D * S_pad * sizeof(short) + (size_t)2 * S_pad * sizeof(float) + 32 * TROW;
+    unsigned char *mine = smem + (size_t)h * per_wave;
+    short *Kt = reinterpret_cast<short *>(mine);                    // [8][S_pad]
+    short *Qt = Kt + (size_t)D * S_pad;
+    short *dOt = Qt + (size_t)D * S_pad;
+    float *lse_s = reinterpret_cast<float *>(dOt + (size_t)D * S_pad);
+    float *delta_s = lse_s + S_pad;
+    char *stg = reinterpret_cast<char *>(delta_s + S_pad);          // [32 rows = keys of the tile (16..31 stay zero)][32 queries] bf16
+    const short *base = reinterpret_cast<const short *>(qkv);
+    const short *obase = reinterpret_cast<const short *>(outp);
+    const short *dobase = reinterpret_cast<const short *>(dout);
+    const size_t row_stride = bm ? (size_t)3 * E : (size_t)B * 3 * E, orow = bm ? (size_t)E : (size_t)B * E;
+    const size_t head_off = (size_t)b * 3 * E * (bm ? S : 1) + (size_t)h * D, ohead = (size_t)b * E * (bm ? S : 1) + (size_t)h * D;
+
+    for (int s = lane; s < S_pad; s += 64) {
+        uint4 qv = make_uint4(0, 0, 0, 0), kv = qv, dov = qv, ov = qv;
+        float ls = 1e30f;
+        if (s < S) {
+            qv = *reinterpret_cast<const uint4 *>(base + (size_t)s * row_stride + head_off);
+            kv = *reinterpret_cast<const uint4 *>(base + (size_t)s * row_stride + head_off + E);
+            dov = *reinterpret_cast<const uint4 *>(dobase + (size_t)s * orow + ohead);
+            ov = *reinterpret_cast<const uint4 *>(obase + (size_t)s * orow + ohead);
+            ls = lse[((size_t)b * HEADS + h) * S + s] * 1.44269504088896341f;
+        }
+        const short *q8 = reinterpret_cast<const short *>(&qv), *k8 = reinterpret_cast<const short *>(&kv);
+        const short *d8 = reinterpret_cast<const short *>(&dov), *o8 = reinterpret_cast<const short *>(&ov);
+        float delta = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            Kt[(size_t)d * S_pad + s] = k8[d];
+            Qt[(size_t)d * S_pad + s] = q8[d];
+            dOt[(size_t)d * S_pad + s] = d8[d];
+            delta += __uint_as_float((uint32_t)(uint16_t)d8[d] << 16) * __uint_as_float((uint32_t)(uint16_t)o8[d] << 16);
+        }
+        lse_s[s] = ls; delta_s[s] = delta;
+    }
+    for (int i = lane; i < 32 * TROW / 4; i += 64) reinterpret_cast<uint32_t *>(stg)[i] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // each head's LDS is private to its wavefront: no block barrier
+    __builtin_amdgcn_wave_barrier();
+
+    const int g = lane >> 4, c = lane & 15;
+    const pmx_bf16x8 zero8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    const pmx_f32x4 z4 = { 0.f, 0.f, 0.f, 0.f };
+    const int n_t = (S + 15) >> 4;
+    const float c2 = scale * 1.44269504088896341f;
+    short *dbase = reinterpret_cast<short *>(dqkv);
+    auto row8 = [&](const short *src, size_t stride, size_t off, int r) -> pmx_bf16x8 {
+        pmx_bf16x8 v = zero8;
+        if (g == 0 && r < S) v = *reinterpret_cast<const pmx_bf16x8 *>(src + (size_t)r * stride + off);
+        return v;
+    };
+    auto tfrag = [&](const short *T, int pair) -> pmx_bf16x8 {
+        pmx_bf16x8 v = zero8;
+        if (c < D) {
+            const short *p = T + (size_t)c * S_pad + pair * 32 + g * 4;
+            const uint2 lo = *reinterpret_cast<const uint2 *>(p), hi = *reinterpret_cast<const uint2 *>(p + 16);
+            const uint4 both = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            v = *reinterpret_cast<const pmx_bf16x8 *>(&both);
+        }
+        return v;
+    };
+    pmx_bf16x8 qr[2 * NPF], dr[2 * NPF];
+    pmx_f32x4 dq[2 * NPF];
+#pragma unroll
+    for (int t = 0; t < 2 * NPF; ++t) {
+        qr[t] = row8(base, row_stride, head_off, t * 16 + c);
+        dr[t] = row8(dobase, orow, ohead, t * 16 + c);
+        dq[t] = z4;
+    }
+    const int tr_row = (lane & 15) >> 2, tr_pc = lane & 3;
+    for (int kt = 0; kt < n_t; ++kt) {
+        const int k_row = kt * 16 + c;
+        const pmx_bf16x8 kf = row8(base, row_stride, head_off + E, k_row);
+        const pmx_bf16x8 vf = row8(base, row_stride, head_off + 2 * E, k_row);
+        // A operand of dQ^T += K^T . dS^T for this key tile: row d = c, k-slot (g, j) = key 16 kt + 8 g + j (groups 2, 3: none)
+        pmx_bf16x8 ka = zero8;
+        if (c < D && g < 2) ka = *reinterpret_cast<const pmx_bf16x8 *>(Kt + (size_t)c * S_pad + kt * 16 + 8 * g);
+        pmx_f32x4 dk = z4, dv = z4;
+#pragma unroll
+        for (int qp = 0; qp < NPF; ++qp) {
+            const pmx_f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[2 * qp], kf, z4, 0, 0, 0);
+            const pmx_f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[2 * qp + 1], kf, z4, 0, 0, 0);
+            const pmx_f32x4 p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dr[2 * qp], vf, z4, 0, 0, 0);
+            const pmx_f32x4 p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dr[2 * qp + 1], vf, z4, 0, 0, 0);
+            pmx_bf16x8 pf, dsf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qa = qp * 32 + g * 4 + r, qb = qa + 16;
+                const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c2, -lse_s[qa]));
+                const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c2, -lse_s[qb]));
+                pf[r] = pmx_f2bf(e0); pf[4 + r] = pmx_f2bf(e1);
+                dsf[r] = pmx_f2bf(e0 * (p0[r] - delta_s[qa]));
+                dsf[4 + r] = pmx_f2bf(e1 * (p1[r] - delta_s[qb]));
+            }
+            dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(dOt, qp), pf, dv, 0, 0, 0);
+            dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Qt, qp), dsf, dk, 0, 0, 0);
+            // dS of the tile as [key c][queries 4g .. 4g+3 | 16 + 4g ..] -> staging rows 0..15 (a padded key's column holds whatever
+            // the zero K row produced; its K^T entries in `ka` are zero, so it adds nothing)
+            {
+                const uint4 w = *reinterpret_cast<const uint4 *>(&dsf);
+                *reinterpret_cast<uint2 *>(stg + c * TROW + (4 * g) * 2) = make_uint2(w.x, w.y);
+                *reinterpret_cast<uint2 *>(stg + c * TROW + (16 + 4 * g) * 2) = make_uint2(w.z, w.w);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const char *a0 = stg + (8 * g + tr_row) * TROW + half * 32 + tr_pc * 8;
+                const pmx_bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pmx_bf16x4 __attribute__((address_space(3))) *)(a0));
+                const pmx_bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pmx_bf16x4 __attribute__((address_space(3))) *)(a0 + 4 * TROW));
+                const pmx_bf16x8 bT = { lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3] };
+                dq[2 * qp + half] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, bT, dq[2 * qp + half], 0, 0, 0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the staging rows are rewritten by the next pair
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (k_row < S && g < 2) {
+            short wk[4], wv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { wk[r] = pmx_f2bf(dk[r] * scale); wv[r] = pmx_f2bf(dv[r]); }
+            *reinterpret_cast<uint2 *>(dbase + (size_t)k_row * row_stride + head_off + E + g * 4) = *reinterpret_cast<const uint2 *>(wk);
+            *reinterpret_cast<uint2 *>(dbase + (size_t)k_row * row_stride + head_off + 2 * E + g * 4) = *reinterpret_cast<const uint2 *>(wv);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2 * NPF; ++t) {
+        const int q_row = t * 16 + c;
+        if (q_row < S && g < 2) {
+            short w4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w4[r] = pmx_f2bf(dq[t][r] * scale);
+            *reinterpret_cast<uint2 *>(dbase + (size_t)q_row * row_stride + head_off + g * 4) = *reinterpret_cast<const uint2 *>(w4);
+        }
+    }
+}
+
 // dqkv_dev [S][B][96] bf16 is written in full.  S <= 640 (LDS: 56 * S_pad bytes per wavefront).
 extern "C" int pmx_attn8_backward(const void *qkv_dev, const void *out_dev, const void *dout_dev, const float *lse_dev, void *dqkv_dev,
                                   int32_t S, int32_t B, void *stream)
@@ -1017,6 +1172,14 @@ extern "C" int pmx_attn8_backward_layout(const void *qkv_dev, const void *out_de
         attr_set = true;
     }
     static const bool generic_only = getenv("PMX_ATTN_BWD_GENERIC") != nullptr;      // A/B switch, read once
+    static const bool two_pass = getenv("PMX_ATTN_BWD_TWO_PASS") != nullptr;         // A/B switch, read once
+    if (S_pad == 160 && !generic_only && !two_pass) {
+        // one pass, one wavefront per (sample, head): 4 x (3 x 8 x 160 x 2 + 2 x 160 x 4 + 32 x 80) = 45 KB of LDS
+        constexpr size_t lds_f = (size_t)4 * ((size_t)3 * 8 * 160 * sizeof(short) + (size_t)2 * 160 * sizeof(float) + 32 * 80);
+        hipLaunchKernelGGL(pmx_attn8_bwd_fused_kernel<5>, dim3(B), dim3(256), lds_f, st, (const __hip_bfloat16 *)qkv_dev, (const __hip_bfloat16 *)out_dev,
+                           (const __hip_bfloat16 *)dout_dev, lse_dev, (__hip_bfloat16 *)dqkv_dev, S, B, 0.35355339059327379f, batch_major ? 1 : 0);
+        return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+    }
     if (S_pad == 160 && !generic_only)       // tinyCapture and smallCapture (154 cells): the row operands of a wave fit in 80 registers
         hipLaunchKernelGGL(pmx_attn8_bwd_kernel<5>, dim3(B), dim3(512), lds, st, (const __hip_bfloat16 *)qkv_dev, (const __hip_bfloat16 *)out_dev,
                            (const __hip_bfloat16 *)dout_dev, lse_dev, (__hip_bfloat16 *)dqkv_dev, S, B, 0.35355339059327379f, batch_major ? 1 : 0);
