@@ -109,25 +109,34 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_wave_barrier();
 }
 
+// Cross-lane sums with DPP row operations (v_add_f32 with a lane-permuting source: one vector instruction per step) instead of
+// ds_bpermute round trips through the LDS pipeline: after xor 1, xor 2 (quad permutes), row_half_mirror and row_mirror every
+// lane of a 16-lane row holds the row's sum.
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v)
+{
+#ifdef PMX_ACTOR_NO_DPP         /* A/B: the ds_bpermute form */
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+#endif
+    v += dpp_f<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);       // row_half_mirror
+    v += dpp_f<0x140>(v);       // row_mirror
+    return v;
+}
 // sum over the 32 lanes that share a GroupNorm group in P layout: all p (lane bits 0..3) and g & 1 (bit 4)
 __device__ __forceinline__ float group_sum(float v)
 {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
+    v = row16_sum(v);
     v += __shfl_xor(v, 16, 64);
     return v;
 }
 // sum over the 16 lanes with the same g (same channels, different positions)
-__device__ __forceinline__ float pos_sum(float v)
-{
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
-    return v;
-}
+__device__ __forceinline__ float pos_sum(float v) { return row16_sum(v); }
 
 struct Geom {
     int H, W, WP, HW, MP;
