@@ -132,8 +132,14 @@ __device__ __forceinline__ float row16_sum(float v)
 __device__ __forceinline__ float group_sum(float v)
 {
     v = row16_sum(v);
+#ifdef PMX_ACTOR_NO_DPP
     v += __shfl_xor(v, 16, 64);
     return v;
+#else
+    float a = v, b = v;          // xor-16 step: the odd rows of a swap with the even rows of b (v_permlane16_swap, gfx950)
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+#endif
 }
 // sum over the 16 lanes with the same g (same channels, different positions)
 __device__ __forceinline__ float pos_sum(float v) { return row16_sum(v); }

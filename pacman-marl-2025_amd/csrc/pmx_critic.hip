@@ -58,14 +58,44 @@ __device__ __forceinline__ bf16x8 frag_of(uint32_t a, uint32_t b, uint32_t c, ui
     return __builtin_bit_cast(bf16x8, u);
 }
 
+// Cross-lane sums without the LDS pipeline (ds_bpermute): v_permlane16_swap / v_permlane32_swap (gfx950) exchange the odd rows
+// / upper half of one register with the even rows / lower half of another, so `a = b = v; swap(a, b); a + b` is the xor-16 /
+// xor-32 all-reduce step; within a 16-lane row DPP quad permutes and mirrors do the same as modifiers of the add.
+#ifndef PMX_CRITIC_NO_DPP
+__device__ __forceinline__ float xor16_sum(float v)
+{
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float xor32_sum(float v)
+{
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 // sum over the four lane groups that hold one token's 32 features
+__device__ __forceinline__ float token_sum(float v) { return xor32_sum(xor16_sum(v)); }
+// sum over the 16 tokens of a tile (lanes with the same g)
+__device__ __forceinline__ float tile_sum(float v)
+{
+    v += dpp_f<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);       // row_half_mirror
+    v += dpp_f<0x140>(v);       // row_mirror
+    return v;
+}
+#else
 __device__ __forceinline__ float token_sum(float v)
 {
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
     return v;
 }
-// sum over the 16 tokens of a tile (lanes with the same g)
 __device__ __forceinline__ float tile_sum(float v)
 {
     v += __shfl_xor(v, 1, 64);
@@ -74,6 +104,7 @@ __device__ __forceinline__ float tile_sum(float v)
     v += __shfl_xor(v, 8, 64);
     return v;
 }
+#endif
 
 struct Weights {
     bf16x8 A1[8];        // W1 forward
