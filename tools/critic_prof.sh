@@ -6,4 +6,4 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_critic3
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_critic3 -- python3 $ROOT/tools/critic_bench.py --batch $B --iters 10 > /tmp/prof_critic3.log 2>&1
 cd $ROOT
-python tools/prof_summary.py $(find /tmp/prof_critic3 -name "*kernel_stats.csv" | head -1) "pmx_(ffn|tok)" 8
+python tools/prof_summary.py $(find /tmp/prof_critic3 -name "*kernel_stats.csv" | head -1) "${2:-pmx_(ffn|tok)}" 8
