@@ -36,6 +36,7 @@ WORKLOADS = {
     "mazes8192": ("mazeGenerator", 8192),    # configs[4] per GPU: 65 536 envs on 8 GPUs, seeds 1..65536 (rank r: r*8192+1 ..)
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy ceiling)
+ROOFLINE_MIN_LAUNCHES = 500
 ELEM = {"float32": 4, "bfloat16": 2, "uint8": 1}
 
 
@@ -102,19 +103,59 @@ def cpu_baseline(layout_rows, length, seconds=12.0, layname=None):
                       f"({dt:.1f} s on 1 of {os.cpu_count()} host cores)"}
 
 
-def e2e_probe(layname, dev, rank, world, dist, n_envs, horizon, minibatch, use_graph):
+def emit_team_probe(lay, n_envs, length, dev, rank, actions, launches=ROOFLINE_MIN_LAUNCHES):
+    """The observation kernel the TRAINING loop runs (pmx_emit_team_kernel on byte planes: the two learners' canonicalised
+    observations + the merged critic input of every env, written into rollout-buffer slots), timed like the expansion kernel:
+    start/stop events on each dispatch, >= 500 launches, a tick without observations between two launches as in
+    VecMAPPOTrainer.rollout, and a ring of slots larger than the Infinity Cache so that the bytes have to reach HBM."""
+    import pmx
+    env = pmx.PmxVecEnv(lay, n_envs, length=length, auto_reset=True, obs_dtype="uint8", device=dev, seed=rank)
+    env.reset()
+    H, W = env.layout.height, env.layout.width
+    per = n_envs * 3 * 8 * H * W                                    # algorithmic bytes of one launch (uint8)
+    n_slots = max(4, min(64, (320 << 20) // per + 1))
+    team = torch.empty((n_slots, n_envs, 2, 8, H, W), dtype=torch.uint8, device=dev)
+    merged = torch.empty((n_slots, n_envs, 8, H, W), dtype=torch.uint8, device=dev)
+    n_act = actions.shape[0]
+    for k in range(20):
+        env.step(actions[k % n_act], want_obs=False)
+        env.emit_team_obs(False, team[k % n_slots], merged[k % n_slots])
+    seg, seg_us, tot_ms, tot_n, done = 125, [], 0.0, 0, 0
+    while done < launches:
+        n = min(seg, launches - done)
+        env.profile_begin(n + 8)
+        for k in range(n):
+            env.step(actions[(done + k) % n_act], want_obs=False)
+            env.emit_team_obs(False, team[(done + k) % n_slots], merged[(done + k) % n_slots])
+        pr = env.profile_end()
+        seg_us.append(pr["expand_ms"] * 1e3 / max(pr["expand_launches"], 1))
+        tot_ms += pr["expand_ms"]; tot_n += pr["expand_launches"]
+        done += n
+    avg_s = tot_ms / 1e3 / max(tot_n, 1)
+    checksum = int(team[(done - 1) % n_slots].sum().item()) + int(merged[(done - 1) % n_slots].sum().item())
+    env.close()
+    del team, merged
+    torch.cuda.empty_cache()
+    return {"bound": "hbm", "kernel": "pmx_emit_team_kernel<uint8>", "achieved": per / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": per / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": per,
+            "avg_launch_us": avg_s * 1e6, "launches": tot_n, "segment_avg_us_min_max": [min(seg_us), max(seg_us)],
+            "slots": n_slots, "checksum": checksum,
+            "note": "3 slots (learner, learner, merged) x 8 planes x H x W bytes per env-tick; the product's observation path "
+                    "(VecMAPPOTrainer.rollout), one launch per tick"}
+
+
+def e2e_probe(layout, dev, rank, world, dist, n_envs, horizon, minibatch, use_graph, algorithm="mappo", rehearse_dp=False):
     """One full MAPPO update -- rollout of `horizon` ticks of `n_envs` envs with policy inference, GAE, UPDATE_EPOCHS epochs of
     `minibatch`-sample optimizer steps -- timed end to end after a short warm-up (pacman_mappo_resnet.py:461-600).  With more
-    than one rank every optimizer step all-reduces the flat fp32 gradient bucket over RCCL; the times are
-    bracketed by barriers, the maximum over ranks is reported and the rates are whole-job."""
+    than one rank every optimizer step all-reduces the flat fp32 gradient bucket over RCCL, the actor's slice while the
+    critic's backward runs; the replayed step is then one hipGraph per gradient group with the eager collectives between them.
+    The times are bracketed by barriers, the maximum over ranks is reported and the rates are whole-job.  rehearse_dp: the same
+    collective path on a ONE-rank RCCL group (what a one-GPU box can validate: capture, replay, stream order; not the wire time)."""
     from pmx import trainer
-    force_pg = dist is not None and (world > 1 or os.environ.get("PMX_BENCH_FORCE_DP") == "1")
-    tr = trainer.VecMAPPOTrainer(layname, n_envs, horizon=horizon, minibatch=minibatch, device=dev, opponent="random", rank=rank,
-                                 world_size=world, process_group=dist.group.WORLD if force_pg else None,
-                                 use_graph=use_graph and not force_pg)
-    if force_pg and world == 1:
-        tr.learner.world_size = 2          # rehearsal on a one-GPU box: issue the RCCL all-reduce although there is one rank
-        tr.learner.pg = dist.group.WORLD
+    dp = dist is not None and (world > 1 or rehearse_dp)
+    tr = trainer.VecMAPPOTrainer(layout, n_envs, horizon=horizon, minibatch=minibatch, device=dev, opponent="random", rank=rank,
+                                 world_size=world, process_group=dist.group.WORLD if dp else None, use_graph=use_graph,
+                                 algorithm=algorithm, force_collectives=dp and world == 1)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -145,43 +186,80 @@ def e2e_probe(layname, dev, rank, world, dist, n_envs, horizon, minibatch, use_g
     finite = bool(torch.isfinite(tr.stats["grad_norm"]).item())
     grad_bytes = tr.learner.bucket.grad.numel() * 4
     fused = bool(tr.model._use_fused_tower(tr.obs_buf[0, :1, 0]))
+    graphs = 0 if not tr.use_graph else (len(tr.learner._graphs) if tr.learner._graphs else 1)
+    groups = [int(tr.learner._offsets[hi] - tr.learner._offsets[lo]) * 4 for lo, hi in tr.learner._grad_groups()] if dp else []
     tr.env.close()
     del tr
     torch.cuda.empty_cache()
     env_steps = n_envs * horizon * world
-    return {"end_to_end_env_steps_per_s": env_steps / (t_roll + t_upd), "minibatch_per_gpu": minibatch,
+    return {"end_to_end_env_steps_per_s": env_steps / (t_roll + t_upd), "algorithm": algorithm, "minibatch_per_gpu": minibatch,
             "envs_per_gpu": n_envs, "horizon": horizon, "epochs": 3, "optimizer_steps": steps, "rollout_s": t_roll,
             "gae_plus_update_s": t_upd, "rollout_env_steps_per_s": env_steps / t_roll, "optimizer_steps_per_s": steps / t_upd,
-            "train_samples_per_s": steps * minibatch * world / t_upd, "hipgraph_replay": bool(use_graph and not force_pg),
+            "train_samples_per_s": steps * minibatch * world / t_upd, "hipgraph_replay": bool(graphs), "hipgraphs_per_step": graphs,
             "finite": finite, "fused_actor_tower": fused,
-            "grad_allreduce": (f"one RCCL all-reduce of the flat fp32 gradient bucket ({grad_bytes / 1e6:.1f} MB) per optimizer step"
-                               if (world > 1 or force_pg) else "none (1 GPU)")}
+            "grad_allreduce": (f"RCCL all-reduce (mean) of the flat fp32 gradient bucket ({grad_bytes / 1e6:.1f} MB) per optimizer step in "
+                               f"{len(groups)} slices of {[round(g / 1e6, 2) for g in groups]} MB (actor first, in flight during the critic's "
+                               f"backward)" + (" -- ONE-rank rehearsal" if world == 1 else "")) if dp else "none (1 GPU)"}
 
 
-def ppo_probe(layname, dev, rank=0, world=1, dist=None, n_envs=16384, horizon=32, large_minibatch=16384):
-    """The second half of BASELINE.json's metric: end-to-end MAPPO on BASELINE config 3 (smallCapture, 16 384 envs per GPU,
-    T = 32, 3 epochs), once at the reference's minibatch of 512 samples per GPU (pacman_mappo_resnet.py:18; replayed from a
-    hipGraph on one GPU, where the step is launch-bound) and once at a large minibatch (fewer, larger optimizer steps -- a
-    different optimisation schedule than the reference's, stated as such)."""
-    runs = []
-    for mb, graph in ((512, world == 1), (large_minibatch, False)):
-        try:
-            runs.append(e2e_probe(layname, dev, rank, world, dist, n_envs, horizon, mb, graph))
-        except Exception as e:                      # the probe must not lose the bench line
-            runs.append({"minibatch_per_gpu": mb, "error": f"{type(e).__name__}: {e}"})
+NETWORK_NOTE = ("MAPPOAgent: actor tower = one fused HIP forward kernel + two backward kernels on bf16 MFMA (csrc/pmx_actor.hip; boards of 10, "
+                "11 and 28 position tiles = tiny, small and the 20x20 boards); critic batch-major / channels-last: MFMA attention, fused "
+                "in-projection, out-projection + LayerNorm and feed-forward + LayerNorm kernels (csrc/pmx_critic.hip, pmx_train.hip); heads and "
+                "the projector convolution on hipBLASLt / MIOpen")
+
+
+def _safe(fn, *a, **kw):
+    try:
+        return fn(*a, **kw)
+    except Exception as e:                      # a probe must not lose the bench line
+        return {"error": f"{type(e).__name__}: {e}", "minibatch_per_gpu": a[7] if len(a) > 7 else None}
+
+
+def ppo_probe(layname, layout, dev, rank=0, world=1, dist=None, n_envs=16384, horizon=32, large_minibatch=16384, rehearsal_dist=None,
+              algorithms=("mappo",)):
+    """The second half of BASELINE.json's metric: end-to-end MAPPO (rollout with policy inference + GAE + 3 PPO epochs) on the
+    workload, once at the reference's minibatch of 512 samples per GPU (pacman_mappo_resnet.py:18; replayed from hipGraphs, where
+    the step is launch-bound) and once at a large minibatch (fewer, larger optimizer steps -- a different optimisation schedule
+    than the reference's, stated as such).  On one GPU the data-parallel step is rehearsed as well (one-rank RCCL group)."""
+    runs, rehearsal, other = [], [], {}
+    for mb, graph in ((512, True), (large_minibatch, False)):
+        runs.append(_safe(e2e_probe, layout, dev, rank, world, dist, n_envs, horizon, mb, graph))
+    if world == 1 and rehearsal_dist is not None:
+        for mb, graph in ((512, True), (large_minibatch, False)):
+            rehearsal.append(_safe(e2e_probe, layout, dev, rank, world, rehearsal_dist, n_envs, horizon, mb, graph, rehearse_dp=True))
+    for alg in algorithms:
+        if alg != "mappo":
+            other[alg] = _safe(e2e_probe, layout, dev, rank, world, dist, n_envs, horizon, large_minibatch, False, algorithm=alg)
     ref, big = runs
-    return {"config": f"{layname}, {n_envs} envs/GPU, horizon {horizon}, 3 epochs, paired minibatches (the centralised critic runs once "
-                      "per env-tick pair), bf16 autocast, byte observation planes, in-kernel randomTeam opponent",
-            "end_to_end": runs,
-            "end_to_end_env_steps_per_s": big.get("end_to_end_env_steps_per_s"), "end_to_end_minibatch": large_minibatch,
-            "end_to_end_env_steps_per_s_mb512": ref.get("end_to_end_env_steps_per_s"),
-            "optimizer_steps_per_s": ref.get("optimizer_steps_per_s"), "samples_per_gpu_per_step": 512,
-            "rollout_env_steps_per_s": big.get("rollout_env_steps_per_s"),
-            "network": "MAPPOAgent: actor tower = one fused HIP forward kernel + two backward kernels on bf16 MFMA "
-                       "(csrc/pmx_actor.hip); critic batch-major / channels-last: MFMA attention, fused in-projection, out-projection + LayerNorm and "
-                       "feed-forward + LayerNorm kernels (csrc/pmx_critic.hip, pmx_train.hip); heads and the projector convolution on hipBLASLt / MIOpen",
-            "reference_cpu": "0.49 s per optimizer step (2 steps/s) and about 80 env-steps/s end to end on 8 host cores, smallCapture "
-                             "(tools/time_reference.py, profiles/r01_cpu_reference_ratio.json)"}
+    out = {"config": f"{layname}, {n_envs} envs/GPU, horizon {horizon}, 3 epochs, paired minibatches (the centralised critic runs once "
+                     "per env-tick pair), bf16 autocast, byte observation planes, in-kernel randomTeam opponent",
+           "end_to_end": runs,
+           "end_to_end_env_steps_per_s": big.get("end_to_end_env_steps_per_s"), "end_to_end_minibatch": large_minibatch,
+           "end_to_end_env_steps_per_s_mb512": ref.get("end_to_end_env_steps_per_s"),
+           "optimizer_steps_per_s": ref.get("optimizer_steps_per_s"), "samples_per_gpu_per_step": 512,
+           "rollout_env_steps_per_s": big.get("rollout_env_steps_per_s"),
+           "network": NETWORK_NOTE,
+           "reference_cpu": "0.49 s per optimizer step (2 steps/s) and about 80 env-steps/s end to end on 8 host cores, smallCapture; 1.24 s "
+                            "per step and about 25 env-steps/s on the 20x20 board (tools/time_reference.py, "
+                            "profiles/r01_cpu_reference_ratio.json)"}
+    if rehearsal:
+        out["data_parallel_rehearsal_one_rank"] = rehearsal
+    out.update(other)
+    return out
+
+
+def config5_probe(dev, rank, world, dist, n_envs=8192, horizon=32, minibatch=16384):
+    """BASELINE config 5 per GPU: 8 192 envs, each on its own generated 20x20 maze (mazeGenerator seeds 1..), MAPPO and IPPO end to
+    end (IPPO = the same network with the critic fed each agent's own observation; the reference has no IPPO, so that row has no
+    parity target)."""
+    import pmx
+    from pmx import maze_generator
+    lays = [pmx.Layout.from_text(maze_generator.generate_maze(seed)) for seed in range(rank * n_envs + 1, (rank + 1) * n_envs + 1)]
+    out = {"config": f"{n_envs} envs/GPU each on its own generated 20x20 maze (seeds {rank * n_envs + 1}..), horizon {horizon}, 3 epochs, "
+                     f"{minibatch}-sample minibatches per GPU, bf16 autocast, byte observation planes, in-kernel randomTeam opponent"}
+    for alg in ("mappo", "ippo"):
+        out[alg] = _safe(e2e_probe, lays, dev, rank, world, dist, n_envs, horizon, minibatch, False, algorithm=alg)
+    return out
 
 
 def main():
@@ -195,6 +273,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-unidirectional", action="store_true", help="skip the pass with a consumer between ticks (for profiler runs)")
     ap.add_argument("--no-ppo", action="store_true", help="skip the short MAPPO rollout/update probe")
+    ap.add_argument("--no-dp-rehearsal", action="store_true", help="skip the one-rank RCCL rehearsal of the data-parallel optimizer step")
+    ap.add_argument("--no-emit", action="store_true", help="skip the pmx_emit_team_obs (training-loop observation kernel) pass")
+    ap.add_argument("--no-config5", action="store_true", help="skip the 20x20 generated-maze MAPPO / IPPO probe of the default run")
     ap.add_argument("--fixed-sweep", action="store_true",
                     help="run EVERY pass with the sweep direction fixed (all bytes to HBM): for profiler runs, so that the trace's average "
                          "duration of the expansion kernel is the one `roofline` is quoted on")
@@ -230,8 +311,6 @@ def main():
     dev = torch.device("cuda", local)
     env = pmx.PmxVecEnv(lay, n_envs, length=length, auto_reset=True, obs_dtype=args.obs, device=dev)
     env.reset()
-    if args.fixed_sweep:
-        env.set_tuning("expand_alt", 0)
     # the action stream: uniform over the 5 actions from the device Philox generator, resident before timing
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     n_act = 64
@@ -243,6 +322,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    # Every timed pass below except `cache_assisted` runs with the sweep direction of the expansion kernel FIXED
+    # (pmx_set_tuning "expand_alt" 0), so that every byte of the planes has to reach HBM.  The library's default alternates the
+    # direction, and a loop like this one -- the same buffer re-stepped with nothing in between -- then overwrites the tail of
+    # tick t while it is still in the 256 MiB Infinity Cache: 16 % faster here, invisible to a caller that consumes the planes.
+    env.set_tuning("expand_alt", 0)
     for k in range(args.warmup):
         env.step(actions[k % n_act])
     barrier()
@@ -260,33 +344,38 @@ def main():
         dt = float(tmax.item())
     checksum = int(env.obs.sum(dtype=torch.float64).item()) if args.obs != "uint8" else int(env.obs.sum().item())
 
-    # second pass, same K steps, with start/stop HIP events attached to each kernel dispatch: per-kernel durations for the roofline
-    env.profile_begin(args.steps + 8)
-    for k in range(args.steps):
-        env.step(actions[k % n_act])
-    prof = env.profile_end()
-    # third pass, the one the roofline is quoted on: the alternating sweep switched off (pmx_set_tuning "expand_alt" 0), so that
-    # every byte of the planes has to reach HBM.  The default alternates the sweep direction, and a loop like this one -- the
-    # same buffer re-stepped with nothing in between -- then overwrites the tail of tick t while it is still in the 256 MiB
-    # Infinity Cache; that figure is reported separately as `cache_assisted`, it is not an HBM rate.
-    # fourth pass: the default sweep again, but with a CONSUMER between ticks that reads the planes and writes a rollout slot
-    # (what VecMAPPOTrainer.rollout does first with every tick's observations): the cache holds the consumer's traffic then.
-    k_uni = min(args.steps, 500)
-    env.set_tuning("expand_alt", 0)
-    t_uni0 = None
+    # roofline pass: start/stop HIP events attached to each kernel dispatch (pmx_profile_begin/end), over AT LEAST 500 launches
+    # whatever --steps is (a 20-launch average moved by 10 % from run to run), in segments whose spread is reported
+    k_roof, seg = max(args.steps, ROOFLINE_MIN_LAUNCHES), 125
+    seg_us, exp_ms, exp_n, rule_ms, rule_n = [], 0.0, 0, 0.0, 0
+    done = 0
+    while done < k_roof:
+        n = min(seg, k_roof - done)
+        env.profile_begin(n + 8)
+        for k in range(n):
+            env.step(actions[(done + k) % n_act])
+        pr = env.profile_end()
+        seg_us.append(pr["expand_ms"] * 1e3 / max(pr["expand_launches"], 1))
+        exp_ms += pr["expand_ms"]; exp_n += pr["expand_launches"]; rule_ms += pr["rule_ms"]; rule_n += pr["rule_launches"]
+        done += n
+    prof_uni = {"expand_ms": exp_ms, "expand_launches": exp_n, "rule_ms": rule_ms, "rule_launches": rule_n}
+    # the library's default path in this loop (alternating sweep): reported as `cache_assisted`, never as `value`
+    k_alt = min(max(args.steps, 100), 500)
+    env.set_tuning("expand_alt", 0 if args.fixed_sweep else -1)
     for k in range(20):
         env.step(actions[k % n_act])
     torch.cuda.synchronize(dev)
-    t_uni0 = time.perf_counter()
-    for k in range(k_uni):
+    t_alt0 = time.perf_counter()
+    for k in range(k_alt):
         env.step(actions[k % n_act])
     torch.cuda.synchronize(dev)
-    tick_uni_s = (time.perf_counter() - t_uni0) / k_uni
-    env.profile_begin(k_uni + 8)
-    for k in range(k_uni):
+    tick_alt_s = (time.perf_counter() - t_alt0) / k_alt
+    env.profile_begin(k_alt + 8)
+    for k in range(k_alt):
         env.step(actions[k % n_act])
-    prof_uni = env.profile_end()
-    env.set_tuning("expand_alt", 0 if args.fixed_sweep else -1)
+    prof = env.profile_end()
+    # the default sweep with a CONSUMER between ticks that reads the planes and writes a rollout slot (what a training loop
+    # does first with every tick's observations): the cache holds the consumer's traffic then
     prof_cons = None
     if not args.no_unidirectional:
         slots = torch.empty((4,) + tuple(env.obs.shape), dtype=env.obs.dtype, device=dev)
@@ -326,6 +415,12 @@ def main():
                 traffic = tj.get(key, {}).get("expand_hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    # the observation kernel of the TRAINING loop: pmx_emit_team_obs on byte planes (two learners' canonicalised planes + the
+    # merged critic input per env-tick, written straight into the rollout buffers); the four-agent expansion above is the
+    # reference-dtype parity path and is not launched by the trainer at all
+    emit = None
+    if not args.no_emit:
+        emit = emit_team_probe(lay, n_envs, length, dev, rank, actions)
 
     if rank == 0:
         B = algorithmic_bytes(H, W, e)
@@ -342,21 +437,26 @@ def main():
             "agent_steps_per_s": 4 * value,
             "algorithmic_bytes_per_env_step": B,
             "tick_GBps": value / world * B / 1e9,
-            "tick_all_bytes_to_hbm": {"us_per_tick": tick_uni_s * 1e6, "GBps": n_envs * B / tick_uni_s / 1e9,
-                                      "frac_of_peak": n_envs * B / tick_uni_s / 1e9 / HBM_PEAK_GBS,
-                                      "note": "whole tick (rule + expansion kernels, host launch path) with the sweep direction fixed"},
+            "tick_all_bytes_to_hbm": {"us_per_tick": dt / args.steps * 1e6, "GBps": n_envs * B / (dt / args.steps) / 1e9,
+                                      "frac_of_peak": n_envs * B / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                                      "note": "whole tick (rule + expansion kernels, host launch path) with the sweep direction fixed: "
+                                              "the loop `value` and `ms_per_step` are taken from"},
             "roofline": {"bound": "hbm", "kernel": "pmx_expand_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "measured_with": "sweep direction fixed (pmx_set_tuning expand_alt 0): every byte of the planes reaches HBM",
                          "traffic_scope": "PMC TCC FETCH_SIZE/WRITE_SIZE = L2 <-> fabric requests; the Infinity Cache sits behind them",
                          "algorithmic_bytes_per_launch": expand_bytes, "avg_launch_us": expand_s * 1e6,
                          "launches": prof_uni["expand_launches"], "rule_kernel_avg_us": rule_s * 1e6,
+                         "segment_avg_us_min_max": [min(seg_us), max(seg_us)],
+                         "frac_min_max": [expand_bytes / (max(seg_us) * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                          expand_bytes / (min(seg_us) * 1e-6) / 1e9 / HBM_PEAK_GBS],
                          "same_device_fill_GBps": write_ceiling,
                          "cache_assisted": {
                              "avg_launch_us": expand_alt_s * 1e6, "GBps": expand_bytes / expand_alt_s / 1e9,
-                             "note": "the default path in THIS loop (same buffer re-stepped, nothing in between): the sweep direction "
-                                     "alternates and tick t+1 overwrites the tail of tick t while it is still in the 256 MiB Infinity "
-                                     "Cache; algorithmic bytes / time, NOT an HBM rate (`value` and `ms_per_step` are from this path)"},
+                             "us_per_tick": tick_alt_s * 1e6, "env_steps_per_s": n_envs / tick_alt_s,
+                             "note": "the library's default path in THIS loop (same buffer re-stepped, nothing in between): the sweep "
+                                     "direction alternates and tick t+1 overwrites the tail of tick t while it is still in the 256 MiB "
+                                     "Infinity Cache; algorithmic bytes / time, NOT an HBM rate, and not what `value` is quoted on"},
                          "with_consumer": None if prof_cons is None else {
                              "avg_launch_us": prof_cons["expand_ms"] * 1e3 / max(prof_cons["expand_launches"], 1),
                              "GBps": expand_bytes / (prof_cons["expand_ms"] / 1e3 / max(prof_cons["expand_launches"], 1)) / 1e9,
@@ -364,15 +464,40 @@ def main():
                                      "many bytes elsewhere)"}},
             "obs_checksum": checksum,
         }
+        if emit is not None:
+            line["roofline_emit_team"] = emit
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(lay[0].text if isinstance(lay, list) else lay.text, length, layname=layname)
     env.close()
-    ppo = None
-    if not args.no_ppo and layname != "mazeGenerator":
-        ppo = ppo_probe(layname, dev, rank, world, dist)
+    ppo = cfg5 = None
+    if not args.no_ppo:
+        rehearsal_dist = None
+        if world == 1 and dist is None and not args.no_dp_rehearsal:
+            try:            # a one-rank RCCL group for the data-parallel rehearsal of the optimizer step
+                import socket
+                import torch.distributed as rdist
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+                rdist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                         device_id=torch.device("cuda", local))
+                rehearsal_dist = rdist
+            except Exception as e:
+                print(f"bench: no one-rank RCCL group for the rehearsal ({type(e).__name__}: {e})", file=sys.stderr)
+        elif dist is not None and world == 1:
+            rehearsal_dist = dist
+        if layname == "mazeGenerator" or layname == "bloxCapture":
+            ppo = ppo_probe(layname, lay, dev, rank, world, dist, n_envs=n_envs, rehearsal_dist=None, algorithms=("mappo", "ippo"))
+        else:
+            ppo = ppo_probe(layname, lay, dev, rank, world, dist, rehearsal_dist=rehearsal_dist)
+            if not args.no_config5:
+                cfg5 = config5_probe(dev, rank, world, dist)
+        if rehearsal_dist is not None and dist is None:
+            rehearsal_dist.destroy_process_group()
     if rank == 0:
         if ppo is not None:
             line["ppo"] = ppo
+        if cfg5 is not None:
+            line["ppo_config5"] = cfg5
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

@@ -191,7 +191,8 @@ int pmx_maze_distances_layout(pmx_env *env, int32_t layout, int8_t *cells_dev, u
 /* Measurement hooks (no reference counterpart): between begin and end, every tick attaches a start and a stop HIP event
  * to its rule-kernel and to its expansion-kernel dispatch on the caller's stream (hipExtLaunchKernelGGL); end
  * synchronises them and returns the summed kernel durations (milliseconds) and launch counts.  bench.py's roofline
- * figures come from here. */
+ * figures come from here.  A pmx_emit_team_obs launch is recorded with the expansion launches (a training loop calls it in
+ * place of the four-agent expansion). */
 int pmx_profile_begin(pmx_env *env, int32_t max_launches);
 /* Launch tuning of the observation-expansion kernel for A/B measurements (no reference counterpart).  key: "expand_alt"
  * (1 = walk the planes in alternating directions from tick to tick, the default; 0 = always the same direction, so that every
@@ -306,8 +307,9 @@ int pmx_flatten_to_f32(int32_t n, const void *const *src_dev, const uint8_t *src
  * MAPPOAgent.actor_backbone (pacman_mappo_resnet.py:104-113 with ResidualBlock :49-67):
  *   conv3x3(8->16) GELU conv3x3(16->32) GELU 3 x [conv3x3 GroupNorm(4) GELU conv3x3 GroupNorm(4) (+x) GELU], bf16 matrix-core
  *   products with fp32 accumulation, GroupNorm and GELU in fp32 on the bf16-rounded convolution output (what bf16 autocast
- *   computes).  Boards whose padded area H*(W+2) needs 10 or 11 position tiles of 16 are supported (tinyCapture,
- *   smallCapture); pmx_actor_supported() says so and callers keep the library convolutions for the rest.
+ *   computes).  Boards whose padded area H*(W+2) needs 10, 11 or 28 position tiles of 16 are supported (tinyCapture,
+ *   smallCapture; the 20 x 20 boards: bloxCapture and the generated mazes); pmx_actor_supported() says so and callers keep the
+ *   library convolutions for the rest.
  * Parameters arrive as float32 device pointers in nn.Module order: conv_w[l] is [cout][cin][3][3], l = 0,1 the stem, then
  * conv1 / conv2 of the three blocks; gn_w / gn_b [6][32] are gn1, gn2 of the three blocks. */
 typedef struct {
@@ -319,8 +321,9 @@ typedef struct {
 #define PMX_ACTOR_PACK_BYTES 297984    /* bf16 operand fragments of the 8 layers (forward + input-gradient order) + fp32 biases / GroupNorm affine */
 #define PMX_ACTOR_GRAD_FLOATS 74496    /* backward's fp32 gradient buffer: weight-gradient tiles + bias / GroupNorm gradients */
 int pmx_actor_supported(int32_t H, int32_t W);
-/* bytes of the activation save area (training forward -> backward) and of backward's scratch, for B samples */
-int pmx_actor_sizes(int32_t H, int32_t W, int64_t B, int64_t *save_bytes, int64_t *scratch_bytes);
+/* bytes of the activation save area (training forward -> backward) and of backward's scratch for B samples, and of the
+ * scratch an inference-only forward needs (independent of B); any of the three pointers may be NULL */
+int pmx_actor_sizes(int32_t H, int32_t W, int64_t B, int64_t *save_bytes, int64_t *scratch_bytes, int64_t *infer_scratch_bytes);
 /* parameters -> pack_dev [PMX_ACTOR_PACK_BYTES]; once per optimizer step (the weights changed) or once per rollout */
 int pmx_actor_pack(const pmx_actor_params *params, void *pack_dev, void *stream);
 /* obs_dev [B][8][H][W] of PMX_OBS_* elements -> feat_dev [B][H*W][32] bfloat16 (channels-last; the reference's nn.Flatten order

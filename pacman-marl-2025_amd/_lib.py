@@ -95,7 +95,7 @@ PROTOTYPES = [
     ("pmx_canonicalize_obs", C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _VP]),
     ("pmx_merge_obs", C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
     ("pmx_actor_supported", C.c_int, [_I32, _I32]),
-    ("pmx_actor_sizes", C.c_int, [_I32, _I32, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("pmx_actor_sizes", C.c_int, [_I32, _I32, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("pmx_actor_pack", C.c_int, [C.POINTER(ActorParams), _VP, _VP]),
     ("pmx_actor_forward", C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, C.c_int64, _I32, _I32, _VP]),
     ("pmx_actor_backward", C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, _VP, C.c_int64, _I32, _I32, _VP]),

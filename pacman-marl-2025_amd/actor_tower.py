@@ -56,33 +56,36 @@ def pack_params(tensors):
 
 
 def _sizes(H, W, B):
+    """-> (save bytes, backward scratch bytes, inference scratch bytes) for B samples"""
     lib = _lib.load()
-    sv, sc = C.c_int64(), C.c_int64()
-    _lib.check(lib.pmx_actor_sizes(H, W, B, C.byref(sv), C.byref(sc)), "pmx_actor_sizes")
-    return sv.value, sc.value
+    sv, sc, si = C.c_int64(), C.c_int64(), C.c_int64()
+    _lib.check(lib.pmx_actor_sizes(H, W, B, C.byref(sv), C.byref(sc), C.byref(si)), "pmx_actor_sizes")
+    return sv.value, sc.value, si.value
 
 
-_scratch = {}
+_infer_scratch = {}
 
 
-def _scratch_buffer(dev, nbytes):
-    """One grow-only scratch buffer per device (inference skip inputs / backward's inter-layer gradients)."""
-    buf = _scratch.get(dev)
-    if buf is None or buf.numel() < nbytes:
+def _infer_scratch_buffer(dev, nbytes):
+    """The inference kernels' skip-input slots: one buffer per device whose size depends on the board only (2 048 slots), so
+    it is allocated once per board size and never replaced by a larger batch.  Kernels on one stream use it one after the
+    other; callers that run inference on several streams of one device at once must pass their own `scratch`."""
+    key = (dev, int(nbytes))
+    buf = _infer_scratch.get(key)
+    if buf is None:
         buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _scratch[dev] = buf
+        _infer_scratch[key] = buf
     return buf
 
 
-def tower_forward(obs, pack, save=None):
+def tower_forward(obs, pack, save=None, scratch=None):
     """obs [B,8,H,W] (uint8 / bfloat16 / float32, contiguous) -> features [B, H*W, 32] bfloat16 (channels-last)."""
     lib = _lib.load()
     B, _, H, W = obs.shape
     obs = obs.contiguous()
     feat = torch.empty((B, H * W, 32), dtype=torch.bfloat16, device=obs.device)
-    scratch = None
-    if save is None:
-        scratch = _scratch_buffer(obs.device, _sizes(H, W, B)[1])
+    if save is None and scratch is None:
+        scratch = _infer_scratch_buffer(obs.device, _sizes(H, W, B)[2])
     _lib.check(lib.pmx_actor_forward(obs.data_ptr(), _OBS_CODE[obs.dtype], pack.data_ptr(), feat.data_ptr(),
                                      save.data_ptr() if save is not None else None,
                                      scratch.data_ptr() if scratch is not None else None, B, H, W, _stream(obs.device)),
@@ -96,8 +99,7 @@ class _ActorTower(torch.autograd.Function):
         B, _, H, W = obs.shape
         obs = obs.contiguous()
         pack = pack_params(params)
-        save_bytes, _ = _sizes(H, W, B)
-        save = torch.empty(save_bytes, dtype=torch.uint8, device=obs.device)
+        save = torch.empty(_sizes(H, W, B)[0], dtype=torch.uint8, device=obs.device)
         feat = tower_forward(obs, pack, save)
         ctx.save_for_backward(obs, pack, save)
         ctx.shapes = [tuple(p.shape) for p in params]
@@ -111,7 +113,11 @@ class _ActorTower(torch.autograd.Function):
         B, _, H, W = obs.shape
         dev = obs.device
         dfeat = dfeat.to(torch.bfloat16).contiguous()
-        scratch = _scratch_buffer(dev, _sizes(H, W, B)[1])
+        # backward's scratch belongs to THIS call (a stream-ordered allocation from the caching allocator; under hipGraph capture
+        # it comes from the graph's private pool and lives as long as the graph).  A module-global grow-only buffer could be
+        # replaced -- and its old block handed to another tensor -- by a later, larger call while a captured graph still
+        # replays a backward that writes through the old pointer.
+        scratch = torch.empty(_sizes(H, W, B)[1], dtype=torch.uint8, device=dev)
         grad = torch.empty(_lib.ACTOR_GRAD_FLOATS, dtype=torch.float32, device=dev)
         _lib.check(lib.pmx_actor_backward(obs.data_ptr(), _OBS_CODE[obs.dtype], pack.data_ptr(), save.data_ptr(), dfeat.data_ptr(),
                                           scratch.data_ptr(), grad.data_ptr(), B, H, W, _stream(dev)), "pmx_actor_backward")

@@ -5,8 +5,8 @@
 //
 // Mapping.  One WAVEFRONT owns one sample from the first convolution to the last; nothing is shared between waves, so
 // there is no barrier anywhere in the forward kernel.  A sample's activation lives in the wave's private LDS map as
-// [padded position][32 channels] bf16 (64 bytes per position, the 16-byte chunks XOR-swizzled with bit 2 of the position
-// so that the ds_read_b128 of an MFMA operand is bank-conflict free).  Positions are the linear index q = (row+1)*(W+2) +
+// [padded position][32 channels] bf16 (64 bytes per position, plain addresses: see map_off).  Positions are the linear index
+// q = (row+1)*(W+2) +
 // (col+1) of the zero-padded board, so a 3x3 tap is a constant shift of q and a tile of 16 consecutive q is one MFMA
 // column block; the two pad columns inside a tile cost 2/16 of the work and are masked to zero on every write, which keeps
 // the padding zero for the next layer.  Every layer is run as 32 -> 32 channels (the stem's missing channels are zero
@@ -875,6 +875,10 @@ __global__ __launch_bounds__(256, WS == 4 ? 2 : 1) void pmx_actor_bwd_data_split
                                                                          int H, int W)
 {
     constexpr int NTW = (NT + WS - 1) / WS, SPB = 4 / WS, KS = (NT + 1) / 2;
+    // large boards (7 tiles per wave): the skip input of a layer is asked for at the top of that layer instead of one layer ahead
+    // -- 28 registers that would be live across the input-gradient convolution next to the parked skip gradient (the kernel
+    // spilled 27 registers at its 256-register budget with them)
+    constexpr bool XG_LATE = NT > 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = lane & 15, g = lane >> 4;
@@ -937,10 +941,11 @@ __global__ __launch_bounds__(256, WS == 4 ? 2 : 1) void pmx_actor_bwd_data_split
             for (int tl = 0; tl < NTW; ++tl)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    hp[tl][m] = xg[tl][m] = uint2{0u, 0u};
+                    hp[tl][m] = uint2{0u, 0u};
+                    if (!XG_LATE) xg[tl][m] = uint2{0u, 0u};
                     if (t0 + tl < NT) {
                         hp[tl][m] = hsave[dump_index((size_t)ln * B + s, NT, t0 + tl, m, lane)];
-                        if (res_n) xg[tl][m] = ysave[dump_index((size_t)lres * B + s, NT, t0 + tl, m, lane)];
+                        if (!XG_LATE && res_n) xg[tl][m] = ysave[dump_index((size_t)lres * B + s, NT, t0 + tl, m, lane)];
                     }
                 }
         };
@@ -955,6 +960,15 @@ __global__ __launch_bounds__(256, WS == 4 ? 2 : 1) void pmx_actor_bwd_data_split
             uint32_t vmk = vmask;
             asm volatile("" : "+s"(WPv));
             asm volatile("" : "+v"(pq), "+v"(vmk));
+            if (XG_LATE) {
+#pragma unroll
+                for (int tl = 0; tl < NTW; ++tl)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        xg[tl][m] = uint2{0u, 0u};
+                        if (has_res && t0 + tl < NT) xg[tl][m] = ysave[dump_index((size_t)(l - 2) * B + s, NT, t0 + tl, m, lane)];
+                    }
+            }
             // ---- pass 1 on the own tiles ---------------------------------------------------------------------------------
             float S1[2] = {0.f, 0.f}, S2[2] = {0.f, 0.f};
             float dgw[2][4], dgb[2][4];
@@ -1267,6 +1281,103 @@ __global__ __launch_bounds__(256, 2) void pmx_actor_bwd_weight_kernel(const IN_T
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The weight gradient for LARGE boards (20 x 20: 28 position tiles, a 31 KB map per sample): TWO waves per sample share the
+// sample's LDS map, two samples per block.  Wave `ni` of a pair keeps the 18 gradient tiles of ITS input-channel half (2
+// output halves x 9 taps, 72 accumulator registers) across the pair's samples: per key-pair block it reads both dH operand
+// fragments from global memory (requested one block ahead) and nine transposed B operands of its channel half from the map
+// -- the same one-LDS-read-per-MFMA ratio as the four-maps-per-block kernel above, at a quarter of its LDS per wave.  The
+// pair's next input activation is fetched into registers (each wave half of the tiles) while the current one is multiplied.
+// Every wave writes its 18 tiles to the pair's partial row; pmx_actor_sum_w_kernel adds the rows.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT, typename IN_T>
+__global__ __launch_bounds__(256, 2) void pmx_actor_bwd_weight_split_kernel(const IN_T *__restrict__ obs, const uint2 *__restrict__ ysave,
+                                                                           const bf16x8 *__restrict__ dasave, float *__restrict__ wpart,
+                                                                           int B, int H, int W, int per_pair)
+{
+    constexpr int KS = (NT + 1) / 2, NTH = (NT + 1) / 2;       // key-pair blocks; tiles each wave of a pair carries into the map
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = lane & 15, g = lane >> 4;
+    const int l = blockIdx.y;
+    const int sub = __builtin_amdgcn_readfirstlane(wave >> 1), ni = __builtin_amdgcn_readfirstlane(wave & 1);
+    Geom G;
+    G.H = H, G.W = W, G.WP = W + 2, G.HW = H * W, G.MP = map_positions(NT, W + 2);
+    char *mapB = smem + (size_t)sub * G.MP * 64;
+    for (int i = threadIdx.x; i < 2 * G.MP * 4; i += 256) reinterpret_cast<uint4 *>(smem)[i] = uint4{0, 0, 0, 0};
+    const int tr_row = (lane & 15) >> 2, tr_pc = lane & 3;
+    f32x4 accw[18];                                             // [output half mo][tap]
+#pragma unroll
+    for (int i = 0; i < 18; ++i) accw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int pair = blockIdx.x * 2 + sub;
+    const int s_begin = pair * per_pair;
+    uint2 xin[NTH][2];
+    auto fetch = [&](int s) {
+#pragma unroll
+        for (int tl = 0; tl < NTH; ++tl)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int t = ni * NTH + tl;
+                xin[tl][m] = uint2{0u, 0u};
+                if (t < NT) xin[tl][m] = ysave[dump_index((size_t)(l - 1) * B + s, NT, t, m, lane)];
+            }
+    };
+    if (l > 0 && s_begin < B) fetch(s_begin);
+    for (int i = 0; i < per_pair; ++i) {
+        const int s = s_begin + i;
+        const bool live = s < B;                                // wave-uniform; the two pairs of a block may differ
+        int WPv = G.WP, pq = p + GUARD;
+        asm volatile("" : "+s"(WPv));
+        asm volatile("" : "+v"(pq));
+        __syncthreads();                                        // the previous sample's map reads are done (and the clear, first time)
+        if (live) {
+            if (l == 0) {
+                load_obs_block<IN_T>(obs + (size_t)s * 8 * G.HW, mapB, G, ni * 64 + lane, 128);
+            } else {
+#pragma unroll
+                for (int tl = 0; tl < NTH; ++tl) {
+                    const int t = ni * NTH + tl;
+                    if (t < NT) {
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+                            *reinterpret_cast<uint2 *>(mapB + pq * 64 + g * 8 + (WPv + 16 * t) * 64 + m * 32) = xin[tl][m];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (l > 0 && i + 1 < per_pair && s + 1 < B) fetch(s + 1);
+        if (live) {
+            const bf16x8 *asrc = dasave + (((size_t)l * B + s) * KS * 2) * 64 + lane;
+            bf16x8 An0 = asrc[0], An1 = asrc[64];
+#pragma unroll 2
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 Ad0 = An0, Ad1 = An1;
+                if (ks + 1 < KS) { An0 = asrc[((ks + 1) * 2 + 0) * 64]; An1 = asrc[((ks + 1) * 2 + 1) * 64]; }
+                const char *tbase = mapB + (8 * g + tr_row + GUARD) * 64 + tr_pc * 8 + (WPv + 32 * ks) * 64 + ni * 32;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const char *tx = tbase + ((ky - 1) * WPv + (kx - 1)) * 64;
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)(tx));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)(tx + 256));
+                        const bf16x8 Bx = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        accw[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ad0, Bx, accw[ky * 3 + kx], 0, 0, 0);
+                        accw[9 + ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ad1, Bx, accw[9 + ky * 3 + kx], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    // the pair's partial row: tile (mo * 2 + ni) * 9 + tap, 64 lanes x 4 floats each (plain stores; every pair writes its row in
+    // full, zeros included, so the row sum needs no memset)
+    float *dst = wpart + ((size_t)pair * NLAYER * 36 + (size_t)l * 36) * 256 + (size_t)lane * 4;
+#pragma unroll
+    for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) *reinterpret_cast<f32x4 *>(dst + (size_t)((mo * 2 + ni) * 9 + k) * 256) = accw[mo * 9 + k];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Parameter packing: fp32 [cout][cin][3][3] weights -> bf16 MFMA A fragments (forward and input-gradient order)
 // ---------------------------------------------------------------------------------------------------------------
 struct PackArgs {
@@ -1333,24 +1444,27 @@ int tiles_for(int H, int W) { return (H * (W + 2) + 15) / 16; }
 static const int kCin[NLAYER] = {8, 16, 32, 32, 32, 32, 32, 32};
 static const int kCout[NLAYER] = {16, 32, 32, 32, 32, 32, 32, 32};
 
+// position tiles with a kernel instantiation: 10 / 11 (tinyCapture 7 x 20, smallCapture 11 x 14: one wave per sample, or 2 / 4
+// waves per sample for small batches) and 28 (the 20 x 20 boards -- bloxCapture, the generated mazes: always four waves per sample)
+static bool tiles_supported(int nt) { return nt == 10 || nt == 11 || nt == 28; }
+constexpr bool large_board(int nt) { return nt > 16; }
+
 extern "C" int pmx_actor_supported(int32_t H, int32_t W)
 {
     if (H < 1 || W < 1 || H > PMX_MAX_DIM || W > PMX_MAX_DIM) return 0;
-    const int nt = tiles_for(H, W);
-    return nt == 10 || nt == 11;
+    return tiles_supported(tiles_for(H, W)) ? 1 : 0;
 }
 
-extern "C" int pmx_actor_sizes(int32_t H, int32_t W, int64_t B, int64_t *save_bytes, int64_t *scratch_bytes)
+extern "C" int pmx_actor_sizes(int32_t H, int32_t W, int64_t B, int64_t *save_bytes, int64_t *scratch_bytes, int64_t *infer_scratch_bytes)
 {
     if (!pmx_actor_supported(H, W) || B < 0) return PMX_ERR_UNSUPPORTED;
     const int64_t dump = (int64_t)tiles_for(H, W) * 1024;            // one P-layout dump of one sample
     if (save_bytes) *save_bytes = B * (8 * dump + 8 * dump + 8 * 4 * 2 * 4);
-    if (scratch_bytes) {
-        const int64_t infer = 2048 * dump;                                     // inference: one skip-input slot per resident wave
-        const int64_t bwd = B * 8 * (int64_t)((tiles_for(H, W) + 1) / 2) * 2048 + infer + 1024 * 768 * 4 +
-                            (int64_t)W_PART_ROWS * NLAYER * 36 * 256 * 4;   // backward: dH operand fragments of the 8 layers + skip slots + the two kernels' partial rows
-        *scratch_bytes = infer > bwd ? infer : bwd;
-    }
+    const int64_t infer = 2048 * dump;                               // inference: one skip-input slot per resident sample
+    if (infer_scratch_bytes) *infer_scratch_bytes = infer;
+    // backward: dH operand fragments of the 8 layers + skip slots + the two kernels' partial rows
+    if (scratch_bytes)
+        *scratch_bytes = B * 8 * (int64_t)((tiles_for(H, W) + 1) / 2) * 2048 + infer + 1024 * 768 * 4 + (int64_t)W_PART_ROWS * NLAYER * 36 * 256 * 4;
     return PMX_OK;
 }
 
@@ -1388,15 +1502,19 @@ namespace {
 
 template <typename K> int allow_lds(K kernel, size_t lds)
 {
-    // per device: the attribute belongs to the function on the CURRENT device
-    static bool done[64] = {};
+    // the attribute belongs to ONE kernel on the CURRENT device: latched per (kernel address, device).  (A static flag inside this
+    // template is shared by every instantiation with the same function-pointer TYPE -- e.g. the <10> and <11> data kernels.)
+    if (lds <= 65536) return PMX_OK;
+    struct Key { const void *fn; int dev; };
+    static Key done[256];
+    static int n_done = 0;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PMX_ERR_HIP;
-    if (lds > 65536 && !done[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return PMX_ERR_HIP;
-        done[dev] = true;
-    }
+    if (hipGetDevice(&dev) != hipSuccess) return PMX_ERR_HIP;
+    const void *fn = reinterpret_cast<const void *>(kernel);
+    for (int i = 0; i < n_done; ++i)
+        if (done[i].fn == fn && done[i].dev == dev) return PMX_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return PMX_ERR_HIP;
+    if (n_done < 256) done[n_done++] = Key{fn, dev};               // (past 256 entries the attribute is simply set again)
     return PMX_OK;
 }
 
@@ -1435,15 +1553,15 @@ int split_waves(int64_t B)
 template <int NT, typename IN_T>
 int launch_fwd(const void *obs, const void *pack, void *feat, void *save, void *scratch, int64_t B, int H, int W, hipStream_t st)
 {
-    const size_t lds = (size_t)4 * map_positions(NT, W + 2) * 64;
     const int64_t dump = (int64_t)NT * 128;                                 // uint2 elements of one dump
     uint2 *hs = reinterpret_cast<uint2 *>(save), *ys = hs ? hs + 8 * B * dump : nullptr;
     float *stt = hs ? reinterpret_cast<float *>(ys + 8 * B * dump) : nullptr;
     uint2 *rtmp = reinterpret_cast<uint2 *>(scratch);
     if (!save && !rtmp) return PMX_ERR_INVALID;
-    if (B <= split_max_batch()) {
-        // small batch: several waves per sample (pmx_actor_fwd_split_kernel); 2 048 skip slots exist in the scratch area
-        const int ws = split_waves(B);
+    if (large_board(NT) || B <= split_max_batch()) {
+        // several waves per sample (pmx_actor_fwd_split_kernel): small batches, and every batch of a large board (its
+        // pre-activations do not fit one wave's registers); 2 048 skip slots exist in the scratch area
+        const int ws = large_board(NT) ? 4 : split_waves(B);
         const int spb = 4 / ws;
         const size_t lds_s = (size_t)spb * map_positions(NT, W + 2) * 64 + (size_t)spb * ws * 8 * sizeof(float);
         int64_t g64 = (B + spb - 1) / spb;
@@ -1456,21 +1574,28 @@ int launch_fwd(const void *obs, const void *pack, void *feat, void *save, void *
         hipLaunchKernelGGL((pmx_actor_fwd_split_kernel<NT, IN_T, SAVEV, WSV>), dim3(grid), dim3(256), lds_s, st, (const IN_T *)obs, \
                            (const char *)pack, (uint2 *)feat, hs, ys, stt, rtmp, (int)B, H, W, 1e-5f);                       \
     } while (0)
-        if (save) { if (ws == 2) PMX_FWD_SPLIT(true, 2); else PMX_FWD_SPLIT(true, 4); }
-        else { if (ws == 2) PMX_FWD_SPLIT(false, 2); else PMX_FWD_SPLIT(false, 4); }
+        if constexpr (large_board(NT)) {
+            if (save) PMX_FWD_SPLIT(true, 4); else PMX_FWD_SPLIT(false, 4);
+        } else {
+            if (save) { if (ws == 2) PMX_FWD_SPLIT(true, 2); else PMX_FWD_SPLIT(true, 4); }
+            else { if (ws == 2) PMX_FWD_SPLIT(false, 2); else PMX_FWD_SPLIT(false, 4); }
+        }
 #undef PMX_FWD_SPLIT
         return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
     }
-    if (save) {
-        int rc = allow_lds(pmx_actor_fwd_kernel<NT, IN_T, true>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL((pmx_actor_fwd_kernel<NT, IN_T, true>), dim3(grid_for(B, 2)), dim3(256), lds, st, (const IN_T *)obs,
-                           (const char *)pack, (uint2 *)feat, hs, ys, stt, rtmp, (int)B, H, W, 1e-5f);
-    } else {
-        int rc = allow_lds(pmx_actor_fwd_kernel<NT, IN_T, false>, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL((pmx_actor_fwd_kernel<NT, IN_T, false>), dim3(grid_for(B, 2)), dim3(256), lds, st, (const IN_T *)obs,
-                           (const char *)pack, (uint2 *)feat, hs, ys, stt, rtmp, (int)B, H, W, 1e-5f);
+    if constexpr (!large_board(NT)) {
+        const size_t lds = (size_t)4 * map_positions(NT, W + 2) * 64;
+        if (save) {
+            int rc = allow_lds(pmx_actor_fwd_kernel<NT, IN_T, true>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((pmx_actor_fwd_kernel<NT, IN_T, true>), dim3(grid_for(B, 2)), dim3(256), lds, st, (const IN_T *)obs,
+                               (const char *)pack, (uint2 *)feat, hs, ys, stt, rtmp, (int)B, H, W, 1e-5f);
+        } else {
+            int rc = allow_lds(pmx_actor_fwd_kernel<NT, IN_T, false>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((pmx_actor_fwd_kernel<NT, IN_T, false>), dim3(grid_for(B, 2)), dim3(256), lds, st, (const IN_T *)obs,
+                               (const char *)pack, (uint2 *)feat, hs, ys, stt, rtmp, (int)B, H, W, 1e-5f);
+        }
     }
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
@@ -1485,26 +1610,27 @@ int launch_bwd(const void *obs, const void *pack, const void *save, const void *
     const uint2 *hs = reinterpret_cast<const uint2 *>(save), *ys = hs + 8 * B * dump;
     const float *stt = reinterpret_cast<const float *>(ys + 8 * B * dump);
     bf16x8 *da = reinterpret_cast<bf16x8 *>(scratch);                       // [8][B][KS * 2][64] operand fragments of dH
-    uint2 *sk = reinterpret_cast<uint2 *>(da + (size_t)8 * B * KS * 2 * 64);  // then one skip-gradient slot per resident wave
+    uint2 *sk = reinterpret_cast<uint2 *>(da + (size_t)8 * B * KS * 2 * 64);  // then one skip-gradient slot per resident sample
     float *accpart = reinterpret_cast<float *>(sk + (size_t)2048 * dump);       // then the data kernel's per-block partial sums
-    const size_t lds_d = (size_t)4 * (mp * 64 + NLAYER * 96 * 4);
-    int rc = allow_lds(pmx_actor_bwd_data_kernel<NT>, lds_d);
-    if (rc) return rc;
+    int rc;
     int grid_d = grid_for(B, 2);
-    if (B <= split_max_batch() && B <= split_bwd_max_batch()) {
-        // small batch: four waves per sample (pmx_actor_bwd_data_split_kernel).  Measured: 256 samples 56 us, 512 samples 69 us
-        // against 118 us for one wave per sample; at 1 024 samples the split kernels (two waves 160 us, four 135 us) lose to the
-        // one-wave kernel (121 us): by then every SIMD has a wave and the kernel runs at its large-batch rate per sample
-        const int ws = split_waves(B), spb = 4 / ws;
+    if (large_board(NT) || (B <= split_max_batch() && B <= split_bwd_max_batch())) {
+        // several waves per sample (pmx_actor_bwd_data_split_kernel): every batch of a large board; small batches otherwise.
+        // Measured on smallCapture: 256 samples 56 us, 512 samples 69 us against 118 us for one wave per sample; at 1 024 samples
+        // the split kernels (two waves 160 us, four 135 us) lose to the one-wave kernel (121 us): by then every SIMD has a wave and
+        // the kernel runs at its large-batch rate per sample
+        const int ws = large_board(NT) ? 4 : split_waves(B), spb = 4 / ws;
         const size_t lds_s = (size_t)spb * mp * 64 + (size_t)4 * NLAYER * 96 * 4 + (size_t)spb * ws * 8 * 4;
         int64_t g64 = (B + spb - 1) / spb;
         if (g64 > 1024) g64 = 1024;                          // accpart has 1 024 rows; the skip slots (2 048) cover grid * spb
         grid_d = (int)g64;
-        if (ws == 2) {
-            rc = allow_lds(pmx_actor_bwd_data_split_kernel<NT, 2>, lds_s);
-            if (rc) return rc;
-            hipLaunchKernelGGL((pmx_actor_bwd_data_split_kernel<NT, 2>), dim3(grid_d), dim3(256), lds_s, st, (const char *)pack,
-                               (const uint2 *)dfeat, hs, ys, stt, da, sk, accpart, (int)B, H, W);
+        if (!large_board(NT) && ws == 2) {
+            if constexpr (!large_board(NT)) {
+                rc = allow_lds(pmx_actor_bwd_data_split_kernel<NT, 2>, lds_s);
+                if (rc) return rc;
+                hipLaunchKernelGGL((pmx_actor_bwd_data_split_kernel<NT, 2>), dim3(grid_d), dim3(256), lds_s, st, (const char *)pack,
+                                   (const uint2 *)dfeat, hs, ys, stt, da, sk, accpart, (int)B, H, W);
+            }
         } else {
             rc = allow_lds(pmx_actor_bwd_data_split_kernel<NT, 4>, lds_s);
             if (rc) return rc;
@@ -1512,27 +1638,49 @@ int launch_bwd(const void *obs, const void *pack, const void *save, const void *
                                (const uint2 *)dfeat, hs, ys, stt, da, sk, accpart, (int)B, H, W);
         }
     } else {
-        hipLaunchKernelGGL((pmx_actor_bwd_data_kernel<NT>), dim3(grid_d), dim3(256), lds_d, st, (const char *)pack, (const uint2 *)dfeat,
-                           hs, ys, stt, da, sk, accpart, (int)B, H, W);
+        if constexpr (!large_board(NT)) {
+            const size_t lds_d = (size_t)4 * (mp * 64 + NLAYER * 96 * 4);
+            rc = allow_lds(pmx_actor_bwd_data_kernel<NT>, lds_d);
+            if (rc) return rc;
+            hipLaunchKernelGGL((pmx_actor_bwd_data_kernel<NT>), dim3(grid_d), dim3(256), lds_d, st, (const char *)pack, (const uint2 *)dfeat,
+                               hs, ys, stt, da, sk, accpart, (int)B, H, W);
+        }
     }
     hipLaunchKernelGGL(pmx_actor_sum_acc_kernel, dim3(NLAYER * 96 / 32), dim3(256), 0, st, (const float *)accpart, grid_d, grad);
     if (hipGetLastError() != hipSuccess) return PMX_ERR_HIP;
-    // weight gradient: layers x sample chunks; about two blocks per CU in total, each wave at least a few samples
-    const size_t lds_w = (size_t)4 * mp * 64;
-    if (lds_w < (size_t)4 * 9 * 64 * 16) return PMX_ERR_UNSUPPORTED;           // the reduction scratch must fit in the maps
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    int64_t chunks = (2 * cus) / NLAYER;
-    if (chunks > W_PART_ROWS) chunks = W_PART_ROWS;
-    int64_t per_wave = (B + chunks * 4 - 1) / (chunks * 4);
-    if (per_wave < 2) per_wave = 2;
-    chunks = (B + per_wave * 4 - 1) / (per_wave * 4);
-    rc = allow_lds(pmx_actor_bwd_weight_kernel<NT, IN_T>, lds_w);
-    if (rc) return rc;
-    float *wpart = accpart + (size_t)1024 * 768;                             // then the weight kernel's per-chunk rows
-    hipLaunchKernelGGL((pmx_actor_bwd_weight_kernel<NT, IN_T>), dim3((unsigned)chunks, NLAYER), dim3(256), lds_w, st, (const IN_T *)obs, ys,
-                       (const bf16x8 *)da, wpart, (int)B, H, W, (int)per_wave);
-    hipLaunchKernelGGL(pmx_actor_sum_w_kernel, dim3(NLAYER * 36 * 256 / 32), dim3(256), 0, st, (const float *)wpart, (int)chunks, grad);
+    float *wpart = accpart + (size_t)1024 * 768;                             // then the weight kernel's partial rows
+    if constexpr (large_board(NT)) {
+        // weight gradient, large boards: layers x blocks of two sample PAIRS-of-waves; a partial row per pair (<= W_PART_ROWS rows),
+        // about two blocks per CU in total
+        int64_t pairs = (2 * (int64_t)cus / NLAYER) * 2;
+        if (pairs > W_PART_ROWS) pairs = W_PART_ROWS;
+        int64_t per_pair = (B + pairs - 1) / pairs;
+        if (per_pair < 2) per_pair = 2;
+        pairs = (B + per_pair - 1) / per_pair;
+        const int64_t blocks = (pairs + 1) / 2;                              // an odd pair count leaves one idle pair: it writes a row of zeros
+        const size_t lds_w = (size_t)2 * mp * 64;
+        rc = allow_lds(pmx_actor_bwd_weight_split_kernel<NT, IN_T>, lds_w);
+        if (rc) return rc;
+        hipLaunchKernelGGL((pmx_actor_bwd_weight_split_kernel<NT, IN_T>), dim3((unsigned)blocks, NLAYER), dim3(256), lds_w, st, (const IN_T *)obs,
+                           ys, (const bf16x8 *)da, wpart, (int)B, H, W, (int)per_pair);
+        hipLaunchKernelGGL(pmx_actor_sum_w_kernel, dim3(NLAYER * 36 * 256 / 32), dim3(256), 0, st, (const float *)wpart, (int)(blocks * 2), grad);
+    } else {
+        // weight gradient: layers x sample chunks; about two blocks per CU in total, each wave at least a few samples
+        const size_t lds_w = (size_t)4 * mp * 64;
+        if (lds_w < (size_t)4 * 9 * 64 * 16) return PMX_ERR_UNSUPPORTED;           // the reduction scratch must fit in the maps
+        int64_t chunks = (2 * cus) / NLAYER;
+        if (chunks > W_PART_ROWS) chunks = W_PART_ROWS;
+        int64_t per_wave = (B + chunks * 4 - 1) / (chunks * 4);
+        if (per_wave < 2) per_wave = 2;
+        chunks = (B + per_wave * 4 - 1) / (per_wave * 4);
+        rc = allow_lds(pmx_actor_bwd_weight_kernel<NT, IN_T>, lds_w);
+        if (rc) return rc;
+        hipLaunchKernelGGL((pmx_actor_bwd_weight_kernel<NT, IN_T>), dim3((unsigned)chunks, NLAYER), dim3(256), lds_w, st, (const IN_T *)obs, ys,
+                           (const bf16x8 *)da, wpart, (int)B, H, W, (int)per_wave);
+        hipLaunchKernelGGL(pmx_actor_sum_w_kernel, dim3(NLAYER * 36 * 256 / 32), dim3(256), 0, st, (const float *)wpart, (int)chunks, grad);
+    }
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
 
@@ -1558,6 +1706,7 @@ extern "C" int pmx_actor_forward(const void *obs_dev, int32_t obs_dtype, const v
     }
 #endif
     if (nt == 10) { PMX_FWD(10) }
+    if (nt == 28) { PMX_FWD(28) }
     PMX_FWD(11)
 #undef PMX_FWD
 }
@@ -1584,6 +1733,7 @@ extern "C" int pmx_actor_backward(const void *obs_dev, int32_t obs_dtype, const 
     }
 #endif
     if (nt == 10) { PMX_BWD(10) }
+    if (nt == 28) { PMX_BWD(28) }
     PMX_BWD(11)
 #undef PMX_BWD
 }

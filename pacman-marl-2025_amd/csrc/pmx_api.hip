@@ -13,7 +13,7 @@ extern "C" hipError_t pmx_launch_rule(const PmxTickParams *p, int H, hipStream_t
 extern "C" hipError_t pmx_launch_rule_agent(const PmxTickParams *p, int H, int agent, hipStream_t st);
 extern "C" hipError_t pmx_launch_reset(const PmxTickParams *p, int H, hipStream_t st);
 extern "C" hipError_t pmx_launch_successor(const PmxTickParams *p, int H, int agent, hipStream_t st);
-extern "C" hipError_t pmx_launch_emit_team(const PmxEmitParams *p, int dtype, hipStream_t st);
+extern "C" hipError_t pmx_launch_emit_team(const PmxEmitParams *p, int dtype, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 extern "C" hipError_t pmx_launch_expand(const PmxExpandParams *p, const PmxExpandTuning *tune, int dtype, hipStream_t st, hipEvent_t ev0,
                                          hipEvent_t ev1);
 extern "C" hipError_t pmx_launch_maze(const PmxLayoutDev *lay_dev, const int16_t *cell_index_dev, int n_cells,
@@ -416,7 +416,10 @@ int pmx_emit_team_obs(pmx_env *env, int team_red, void *team_obs_dev, void *merg
     x.N = env->cfg.n_envs;
     x.red = team_red ? 1 : 0;
     x.lay_H = env->lay.H, x.lay_W = env->lay.W;
-    HIP_TRY(pmx_launch_emit_team(&x, env->cfg.obs_dtype, as_stream(stream)));
+    // profiling: an emit launch is timed like an expansion launch (it takes the expansion's place in a training loop, whose
+    // pmx_step calls pass no observation pointer and therefore launch no expansion of their own)
+    hipEvent_t *ev = prof_pair(env, true);
+    HIP_TRY(pmx_launch_emit_team(&x, env->cfg.obs_dtype, as_stream(stream), ev ? ev[0] : nullptr, ev ? ev[1] : nullptr));
     return PMX_OK;
 }
 

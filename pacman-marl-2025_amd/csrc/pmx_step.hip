@@ -1261,15 +1261,22 @@ __global__ __launch_bounds__(PMX_BLOCK) void pmx_emit_team_kernel(PmxEmitParams 
     }
 }
 
-extern "C" hipError_t pmx_launch_emit_team(const PmxEmitParams *p, int dtype, hipStream_t st)
+// ev0 / ev1 (both or neither): start / stop events of this very dispatch, as in pmx_launch_expand
+extern "C" hipError_t pmx_launch_emit_team(const PmxEmitParams *p, int dtype, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1)
 {
     const long waves = (long)p->N * (p->merged ? 3 : 2);
     const unsigned blocks = (unsigned)((waves + 3) / 4);
+#define PMX_EMIT(DT)                                                                                                          \
+    do {                                                                                                                      \
+        if (ev0) hipExtLaunchKernelGGL(pmx_emit_team_kernel<DT>, dim3(blocks), dim3(PMX_BLOCK), 0, st, ev0, ev1, 0, *p);       \
+        else hipLaunchKernelGGL(pmx_emit_team_kernel<DT>, dim3(blocks), dim3(PMX_BLOCK), 0, st, *p);                           \
+    } while (0)
     switch (dtype) {
-    case 0: hipLaunchKernelGGL(pmx_emit_team_kernel<0>, dim3(blocks), dim3(PMX_BLOCK), 0, st, *p); break;
-    case 1: hipLaunchKernelGGL(pmx_emit_team_kernel<1>, dim3(blocks), dim3(PMX_BLOCK), 0, st, *p); break;
-    default: hipLaunchKernelGGL(pmx_emit_team_kernel<2>, dim3(blocks), dim3(PMX_BLOCK), 0, st, *p); break;
+    case 0: PMX_EMIT(0); break;
+    case 1: PMX_EMIT(1); break;
+    default: PMX_EMIT(2); break;
     }
+#undef PMX_EMIT
     return hipGetLastError();
 }
 

@@ -692,7 +692,7 @@ class PPOLearner:
     norm 0.5 -> Adam(eps 1e-5) -> EMA 0.995 (pacman_mappo_resnet.py:587-595).  Every rank ends each step with bit-identical
     parameters because the clip and the update see the same reduced gradient."""
 
-    def __init__(self, model, lr=LR_START, process_group=None, world_size=1, autocast_dtype=None):
+    def __init__(self, model, lr=LR_START, process_group=None, world_size=1, autocast_dtype=None, force_collectives=False):
         self.model = model
         self.bucket = FlatBucket(model)
         self.ema = self.bucket.data.clone()                              # EMA of the parameters (:365, :593-595)
@@ -703,10 +703,14 @@ class PPOLearner:
         self.betas, self.eps = (0.9, 0.999), 1e-5                        # torch.optim.Adam defaults, eps from :366
         self.pg = process_group
         self.world_size = world_size
+        # data parallel: the gradient exchange is issued when there is more than one rank -- or when a caller rehearses the
+        # collective path on a one-rank group (bench.py on a one-GPU box)
+        self.dp = world_size > 1 or bool(force_collectives)
         self.autocast_dtype = autocast_dtype
         self._w16 = None
         self._sh16 = None
         self._shadow_views = None
+        self._graph = self._graphs = None
 
     def enable_bf16_flat(self):
         """Manual mixed precision instead of autocast for the optimizer step: the network runs on ONE flat bfloat16 copy of
@@ -730,40 +734,94 @@ class PPOLearner:
         fm = SimpleNamespace(evaluate=lambda o, m, a: torch.func.functional_call(self.model, pd, (o, m, a)))
         return ppo_loss(fm, obs, merged, act, old_logp, adv, ret, clip_eps, ent_coef)
 
+    overlap_allreduce = True   # data parallel: reduce the actor's gradient slice while the critic's backward runs
+
+    def _grad_groups(self):
+        """Index ranges [lo, hi) into bucket.params whose gradients are produced -- and, under data parallelism, reduced --
+        together, in the order the backward pass is run: the actor's parameters (a contiguous prefix of the bucket that holds
+        97 % of its bytes: the 4928 -> 512 head), then the critic's.  One range when nothing is exchanged."""
+        n = len(self.bucket.params)
+        if not (self.dp and self.overlap_allreduce and self._w16 is None):
+            return [(0, n)]
+        if getattr(self, "_groups", None) is None:
+            names = [k for k, p in self.model.named_parameters() if p.requires_grad]
+            n_actor = 0
+            while n_actor < n and names[n_actor].startswith("actor_"):
+                n_actor += 1
+            self._groups = [(0, n_actor), (n_actor, n)] if 0 < n_actor < n else [(0, n)]
+            self._offsets = [0]
+            for p in self.bucket.params:
+                self._offsets.append(self._offsets[-1] + p.numel())
+        return self._groups
+
+    def _backward_group(self, loss, lo, hi, retain):
+        """Gradients of bucket.params[lo:hi] into their slice of the flat float32 bucket: one gathering copy instead of
+        loss.backward() (AccumulateGrad ADDS every parameter's gradient into its zeroed view of the bucket -- ~80 small kernels
+        per step on this network, a quarter of the launches of the 512-sample step)."""
+        params = self.bucket.params[lo:hi]
+        targets = list(params)
+        if self._shadow_views is not None:
+            for i, v in self._shadow_views.items():
+                if lo <= i < hi:
+                    targets[i - lo] = v                  # the bfloat16 copy the library op multiplied by
+        grads = torch.autograd.grad(loss, targets, allow_unused=True, retain_graph=retain)
+        dev = self.bucket.grad.device
+        flat = [g.reshape(-1) if g is not None else torch.zeros(p.numel(), dtype=self.bucket.grad.dtype, device=dev)
+                for g, p in zip(grads, params)]
+        first = sum(p.numel() for p in self.bucket.params[:lo])
+        if dev.type == "cuda" and all(g.dtype in (torch.float32, torch.bfloat16) for g in flat):
+            import ctypes as C
+            from . import _lib
+            lib = _lib.load()
+            n = len(flat)
+            flat = [g.contiguous() for g in flat]
+            src = (C.c_void_p * n)(*[g.data_ptr() for g in flat])
+            isb = (C.c_uint8 * n)(*[1 if g.dtype == torch.bfloat16 else 0 for g in flat])
+            cnt = (C.c_int32 * n)(*[g.numel() for g in flat])
+            offs, o = [], first
+            for g in flat:
+                offs.append(o); o += g.numel()
+            off = (C.c_int64 * n)(*offs)
+            st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(lib.pmx_flatten_to_f32(n, src, isb, off, cnt, self.bucket.grad.data_ptr(), st), "pmx_flatten_to_f32")
+        else:
+            total = sum(g.numel() for g in flat)
+            torch.cat([g.to(self.bucket.grad.dtype) for g in flat], out=self.bucket.grad[first:first + total])
+
+    def _reduce_slice(self, lo, hi):
+        """Starts the all-reduce (mean over ranks) of the gradient slice of bucket.params[lo:hi]; returns a closure that makes the
+        current stream wait for it and finishes the mean.  RCCL averages in the collective; gloo (the CPU tests) sums, and the
+        division follows."""
+        import torch.distributed as dist
+        self._grad_groups()
+        a, b = (self._offsets[lo], self._offsets[hi]) if getattr(self, "_offsets", None) else (0, self.bucket.numel)
+        sl = self.bucket.grad[a:b]
+        avg = self.bucket.grad.is_cuda
+        h = dist.all_reduce(sl, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+        def finish():
+            h.wait()
+            if not avg:
+                sl.div_(self.world_size)
+        return finish
+
     def _backward_into_bucket(self, loss):
-        """loss.backward() with the gradient ending up in the flat float32 bucket (zeroed / accumulated the usual way, or
-        copied from the flat bfloat16 gradient in one kernel)."""
-        if self._w16 is None:
-            # one gathering copy instead of loss.backward(): AccumulateGrad ADDS every parameter's gradient into its (zeroed) view
-            # of the bucket -- ~80 small kernels per step on this network, a quarter of the launches of the 512-sample step
-            targets = list(self.bucket.params)
-            if self._shadow_views is not None:
-                for i, v in self._shadow_views.items():
-                    targets[i] = v                           # the bfloat16 copy the library op multiplied by
-            grads = torch.autograd.grad(loss, targets, allow_unused=True)
-            dev = self.bucket.grad.device
-            flat = [g.reshape(-1) if g is not None else torch.zeros(p.numel(), dtype=self.bucket.grad.dtype, device=dev)
-                    for g, p in zip(grads, self.bucket.params)]
-            if dev.type == "cuda" and all(g.dtype in (torch.float32, torch.bfloat16) for g in flat):
-                import ctypes as C
-                from . import _lib
-                lib = _lib.load()
-                n = len(flat)
-                flat = [g.contiguous() for g in flat]
-                src = (C.c_void_p * n)(*[g.data_ptr() for g in flat])
-                isb = (C.c_uint8 * n)(*[1 if g.dtype == torch.bfloat16 else 0 for g in flat])
-                cnt = (C.c_int32 * n)(*[g.numel() for g in flat])
-                offs, o = [], 0
-                for g in flat:
-                    offs.append(o); o += g.numel()
-                off = (C.c_int64 * n)(*offs)
-                st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-                _lib.check(lib.pmx_flatten_to_f32(n, src, isb, off, cnt, self.bucket.grad.data_ptr(), st), "pmx_flatten_to_f32")
-            else:
-                torch.cat([g.to(self.bucket.grad.dtype) for g in flat], out=self.bucket.grad)
+        """The backward pass with the gradient ending up in the flat float32 bucket and, under data parallelism, averaged over the
+        ranks: group by group, each group's all-reduce in flight while the next group's backward runs."""
+        if self._w16 is not None:
+            (g16,) = torch.autograd.grad(loss, (self._w16,))
+            self.bucket.grad.copy_(g16)
+            if self.dp:
+                self._reduce_slice(0, len(self.bucket.params))()
             return
-        (g16,) = torch.autograd.grad(loss, (self._w16,))
-        self.bucket.grad.copy_(g16)
+        groups = self._grad_groups()
+        pending = []
+        for k, (lo, hi) in enumerate(groups):
+            self._backward_group(loss, lo, hi, retain=k + 1 < len(groups))
+            if self.dp:
+                pending.append(self._reduce_slice(lo, hi))
+        for fin in pending:
+            fin()
 
     def _refresh_bf16(self):
         if self._w16 is not None:
@@ -857,11 +915,7 @@ class PPOLearner:
         else:
             self._shadow_views = None
             loss, stats = ppo_loss(self.model, obs, merged, act, old_logp, adv, ret, clip_eps, ent_coef)
-        self._backward_into_bucket(loss)
-        if self.world_size > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.bucket.grad, op=dist.ReduceOp.SUM, group=self.pg)
-            self.bucket.grad.div_(self.world_size)
+        self._backward_into_bucket(loss)                  # (data parallel: includes the gradient all-reduce)
         # clip_grad_norm_(parameters, 0.5): 2-norm of the per-tensor 2-norms (the reference's summation order; a single
         # fp32 reduction over the 2.6 M-element flat buffer is measurably less accurate on the CPU), then scale by
         # max_norm / (norm + 1e-6) if that is < 1
@@ -906,7 +960,7 @@ class PPOLearner:
         self._g_stats = None
         self._g_acc = torch.zeros(6, dtype=torch.float32, device=dev)       # sums of (pg, vl, entropy, clip_frac, loss, grad_norm)
 
-        def body():
+        def seg_loss():
             i = self._g_in
             if self._w16 is not None:
                 loss, stats = self._loss_bf16_flat(i["obs"], i["merged"], i["act"], i["logp"], i["adv"], i["ret"],
@@ -919,11 +973,9 @@ class PPOLearner:
                 self._shadow_views = None
                 loss, stats = ppo_loss(self.model, i["obs"], i["merged"], i["act"], i["logp"], i["adv"], i["ret"],
                                        self._g_sc[2], self._g_sc[3])
-            self._backward_into_bucket(loss)
-            if self.world_size > 1:
-                import torch.distributed as dist
-                dist.all_reduce(self.bucket.grad, op=dist.ReduceOp.SUM, group=self.pg)
-                self.bucket.grad.div_(self.world_size)
+            return loss, stats
+
+        def seg_tail(stats):
             if self._use_fused_tail():
                 gn = self._fused_tail(self._g_sc)
             else:
@@ -945,6 +997,39 @@ class PPOLearner:
             self._g_acc.add_(torch.stack([stats[k].float() for k in self._g_acc_keys]))
             return stats
 
+        # Data parallel: the collectives stay OUTSIDE the graphs (eager RCCL calls, exactly the ones the eager step issues), so
+        # the step is recorded as one graph per gradient group plus one for the optimizer tail:
+        #   graph 0: forward, loss, backward of group 0 (the actor), its gradients into the bucket   | all-reduce of slice 0 starts
+        #   graph 1: backward of group 1 (the critic), its gradients into the bucket                 | ... overlaps this graph
+        #   graph 2: clip, Adam, EMA, weight copies, reports                                          | after both all-reduces
+        # The autograd graph built while graph 0 is recorded is walked again while graph 1 is recorded; all graphs share one
+        # memory pool, so what graph 0 saved for the backward pass stays where graph 1's kernels read it.
+        groups = self._grad_groups() if self._w16 is None else [(0, len(self.bucket.params))]
+        segmented = self.dp
+        state = {}
+
+        def seg_first():
+            state["loss"], state["stats"] = seg_loss()
+            if self._w16 is not None:
+                (g16,) = torch.autograd.grad(state["loss"], (self._w16,))
+                self.bucket.grad.copy_(g16)
+            else:
+                self._backward_group(state["loss"], *groups[0], retain=len(groups) > 1)
+
+        def seg_group(k):
+            self._backward_group(state["loss"], *groups[k], retain=k + 1 < len(groups))
+
+        def run_eager():
+            seg_first()
+            pend = [self._reduce_slice(*groups[0])] if self.dp else []
+            for k in range(1, len(groups)):
+                seg_group(k)
+                if self.dp:
+                    pend.append(self._reduce_slice(*groups[k]))
+            for fin in pend:
+                fin()
+            return seg_tail(state["stats"])
+
         # warm up on a side stream (allocator, MIOpen solver search), restoring the optimizer state afterwards
         saved = [t.clone() for t in (self.bucket.data, self.exp_avg, self.exp_avg_sq, self.ema)]
         self._set_graph_scalars(clip_eps, ent_coef, step=1)
@@ -952,16 +1037,52 @@ class PPOLearner:
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
             for _ in range(3):
-                body()
+                run_eager()
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._g_stats = body()
+        state.clear()
+        if not segmented:
+            self._graph = torch.cuda.CUDAGraph()
+            self._graphs = None
+            with torch.cuda.graph(self._graph):
+                seg_first()
+                for k in range(1, len(groups)):
+                    seg_group(k)
+                self._g_stats = seg_tail(state["stats"])
+        else:
+            self._graphs, pool = [], None
+            for k in range(len(groups) + 1):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    if k == 0:
+                        seg_first()
+                    elif k < len(groups):
+                        seg_group(k)
+                    else:
+                        self._g_stats = seg_tail(state["stats"])
+                pool = g.pool()
+                self._graphs.append(g)
+            self._graph = None
+            self._g_groups = list(groups)
+        state.clear()
         for t, v in zip((self.bucket.data, self.exp_avg, self.exp_avg_sq, self.ema), saved):
             t.copy_(v)
         self._refresh_bf16()
         self._g_batch = batch
+
+    def _replay(self):
+        """Replays the captured step; data parallel: graph per gradient group with that group's all-reduce started behind it (on
+        RCCL's own stream, so it runs beside the next graph), then the optimizer tail."""
+        if self._graphs is None:
+            self._graph.replay()
+            return
+        pend = []
+        for k, (lo, hi) in enumerate(self._g_groups):
+            self._graphs[k].replay()
+            pend.append(self._reduce_slice(lo, hi))
+        for fin in pend:
+            fin()
+        self._graphs[-1].replay()
 
     def _set_graph_scalars(self, clip_eps, ent_coef, step):
         b1, b2 = self.betas
@@ -987,7 +1108,7 @@ class PPOLearner:
         i["logp"].copy_(old_logp); i["adv"].copy_(adv); i["ret"].copy_(ret)
         self.step_count += 1
         self._set_graph_scalars(clip_eps, ent_coef, self.step_count)
-        self._graph.replay()
+        self._replay()
         return self._g_stats
 
     def update_minibatch_graph_gather(self, sources, index, rows_per_index, clip_eps=CLIP_EPS, ent_coef=ENT_COEF_START):
@@ -1014,7 +1135,7 @@ class PPOLearner:
         _lib.check(lib.pmx_gather_rows(n, src, dst, idx, rb, m, nr, st), "pmx_gather_rows")
         self.step_count += 1
         self._set_graph_scalars(clip_eps, ent_coef, self.step_count)
-        self._graph.replay()
+        self._replay()
         return self._g_stats
 
     def ema_state_dict(self):

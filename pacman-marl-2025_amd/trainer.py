@@ -56,7 +56,7 @@ class VecMAPPOTrainer:
     def __init__(self, layout, n_envs, horizon=32, minibatch=512, epochs=UPDATE_EPOCHS, obs_dtype=None,
                  device="cuda:0", seed=0, rank=0, world_size=1, process_group=None, total_updates=2000, length=300,
                  use_autocast=True, opponent="random", use_graph=False, algorithm="mappo", paired_minibatches=True, flat_bf16=False, curriculum_scale=1.0,
-                 env=None, redraw_layouts=False):
+                 env=None, redraw_layouts=False, force_collectives=False):
         self.device = torch.device(device)
         self.rank, self.world_size = rank, world_size
         if obs_dtype is None:
@@ -92,8 +92,10 @@ class VecMAPPOTrainer:
         torch.manual_seed(seed)                                   # identical initial weights on every rank
         self.model = mappo.MAPPOAgent(self.obs_shape, 5, 2).to(self.device)
         self.autocast_dtype = torch.bfloat16 if use_autocast else None
+        # force_collectives: issue the gradient all-reduce on a one-rank group too (bench.py rehearses the collective path on a
+        # one-GPU box with it)
         self.learner = mappo.PPOLearner(self.model, process_group=process_group, world_size=world_size,
-                                        autocast_dtype=self.autocast_dtype)
+                                        autocast_dtype=self.autocast_dtype, force_collectives=force_collectives)
         if world_size > 1:
             import torch.distributed as dist
             dist.broadcast(self.learner.bucket.data, src=0, group=process_group)
@@ -134,8 +136,8 @@ class VecMAPPOTrainer:
         # reference's 512 samples: 1.4x more optimizer steps/s).  Needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (set by the package
         # on import; ROCm 7's graph packet capture corrupts a node after ~230 interleaved replays); the
         # update loop also checks the gradient norm once per update so that a non-finite policy is never sampled from.
-        if use_graph and world_size > 1:
-            raise ValueError("use_graph is validated on one GPU only (the RCCL all-reduce inside a captured graph is not)")
+        # (data parallel: the replayed step is one graph per gradient group with the eager RCCL all-reduce of that group between
+        # them -- PPOLearner.capture -- so the collectives are the ones the eager step issues)
         if use_graph and not mappo.PPOLearner.graph_replay_safe():
             raise ValueError("use_graph needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 exported before HIP initialises (DESIGN.md section 5)")
         self.use_graph = bool(use_graph) and (horizon * n_envs * 2) % minibatch == 0
@@ -352,6 +354,10 @@ class VecMAPPOTrainer:
 
     def load_full(self, path):
         ck = torch.load(path, map_location=self.device, weights_only=True)
+        need = ("data", "ema", "exp_avg", "exp_avg_sq", "step", "update", "total_updates", "pool", "gen", "np_rng")
+        if not isinstance(ck, dict) or any(k not in ck for k in need) or not isinstance(ck["np_rng"], dict) or "keys" not in ck["np_rng"]:
+            raise ValueError(f"{path}: not a full-resume checkpoint of this version (save_full writes the keys {', '.join(need)}; "
+                             "checkpoints written before `total_updates` and the tensor-valued `np_rng` were added are not supported)")
         if int(ck["total_updates"]) != int(self.total_updates):
             raise ValueError(f"checkpoint was written for a schedule of {ck['total_updates']} updates, this trainer has {self.total_updates}")
         self.learner.bucket.data.copy_(ck["data"]); self.learner.ema.copy_(ck["ema"])

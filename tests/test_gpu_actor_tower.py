@@ -62,16 +62,26 @@ def emulated_tower(m, obs, ste=False):
     return x                                    # [B, 32, H, W]
 
 
-@pytest.mark.parametrize("layout", ["smallCapture", "tinyCapture"])
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.uint8])
-def test_tower_forward_matches_torch(layout, dtype):
+def _board(layout):
+    """(H, W) of a named layout, or of the 20 x 20 boards mazeGenerator.py:255-264 produces ("maze")."""
     import pmx
+    if layout == "maze":
+        from pmx import maze_generator
+        lay = pmx.Layout.from_text(maze_generator.generate_maze(7))
+    else:
+        lay = pmx.get_layout(layout)
+    return lay.height, lay.width
+
+
+@pytest.mark.parametrize("layout,B", [("smallCapture", 777), ("tinyCapture", 777), ("bloxCapture", 333), ("maze", 2111)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.uint8])
+def test_tower_forward_matches_torch(layout, B, dtype):
+    # B: not a multiple of the wavefronts per block (ragged tail); 2 111 samples of a 20 x 20 board exceed the 2 048 blocks the
+    # four-waves-per-sample kernel launches, so some blocks walk two samples
     from pmx import actor_tower
-    lay = pmx.get_layout(layout)
-    H, W = lay.height, lay.width
+    H, W = _board(layout)
     assert actor_tower.tower_supported(H, W)
     m = _model(H, W)
-    B = 777                                     # not a multiple of the wavefronts per block: ragged tail
     obs = _obs(B, H, W)
     with torch.no_grad():
         feat = actor_tower.actor_tower(m.actor_backbone, obs.to(dtype))              # [B, HW, 32]
@@ -94,12 +104,11 @@ def test_tower_forward_matches_torch(layout, dtype):
     assert ((a - b).norm() / b.norm()).item() < 5e-2
 
 
-@pytest.mark.parametrize("layout,B", [("smallCapture", 515), ("tinyCapture", 96), ("smallCapture", 3)])
+@pytest.mark.parametrize("layout,B", [("smallCapture", 515), ("tinyCapture", 96), ("smallCapture", 3), ("bloxCapture", 67), ("maze", 5),
+                                      ("bloxCapture", 1)])
 def test_tower_backward_matches_autograd(layout, B):
-    import pmx
     from pmx import actor_tower
-    lay = pmx.get_layout(layout)
-    H, W = lay.height, lay.width
+    H, W = _board(layout)
     m = _model(H, W, seed=3)
     obs = _obs(B, H, W, seed=4)
     g = torch.Generator(device="cuda").manual_seed(5)
@@ -125,7 +134,29 @@ def test_tower_backward_matches_autograd(layout, B):
     assert len(names) == len(params)
 
 
-def test_tower_backward_is_deterministic_up_to_atomics_and_zero_batch():
+@pytest.mark.parametrize("layout,B", [("bloxCapture", 1300), ("smallCapture", 2600)])
+def test_tower_backward_of_a_large_batch_is_the_sum_over_its_parts(layout, B):
+    """Batches beyond one round of blocks (the data kernel of a 20 x 20 board launches at most 1 024 blocks, the weight kernel
+    gives every pair of waves a run of samples): the parameter gradients of the whole batch equal the sum of the gradients of
+    its two halves, each of which is small enough for the single-round paths the float64 test above covers."""
+    from pmx import actor_tower
+    H, W = _board(layout)
+    m = _model(H, W, seed=11)
+    obs = _obs(B, H, W, seed=12).to(torch.uint8)
+    g = torch.Generator(device="cuda").manual_seed(13)
+    dfeat = (torch.randn(B, H * W, 32, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    params = actor_tower._tower_params(m.actor_backbone)
+
+    def grads(lo, hi):
+        feat = actor_tower.actor_tower(m.actor_backbone, obs[lo:hi])
+        return torch.autograd.grad((feat.float() * dfeat[lo:hi].float()).sum(), params)
+    whole, a, b = grads(0, B), grads(0, B // 2), grads(B // 2, B)
+    for w, x, y in zip(whole, a, b):
+        ref = x.double() + y.double()
+        assert ((w.double() - ref).norm() / (ref.norm() + 1e-12)).item() < 2e-4        # float32 sums in another order
+
+
+def test_tower_backward_is_deterministic_and_zero_batch():
     import pmx
     from pmx import actor_tower
     lay = pmx.get_layout("smallCapture")
@@ -138,6 +169,6 @@ def test_tower_backward_is_deterministic_up_to_atomics_and_zero_batch():
         feat = actor_tower.actor_tower(m.actor_backbone, obs)
         outs.append(torch.autograd.grad(feat.float().square().sum(), params))
     for a, b in zip(*outs):
-        assert ((a - b).norm() / (b.norm() + 1e-12)).item() < 1e-5            # float atomics: order-dependent last bits only
+        assert ((a - b).norm() / (b.norm() + 1e-12)).item() < 1e-5            # (the LDS float adds of the per-channel sums may differ in order)
     empty = actor_tower.tower_forward(obs[:0], actor_tower.pack_params(params))
     assert empty.shape == (0, H * W, 32)

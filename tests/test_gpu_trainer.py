@@ -151,6 +151,46 @@ def test_graph_replay_bf16_stays_finite_past_230_replays():
     assert bool(torch.isfinite(L.bucket.data).all())
 
 
+def test_graph_replay_survives_larger_tower_calls_after_capture():
+    """A captured bf16 step replays a fused-tower backward that writes through the scratch pointer recorded at capture.  That
+    scratch must belong to the graph: larger inference and training calls made AFTER the capture (they used to replace a
+    module-global grow-only buffer and hand its old block back to the allocator) must not disturb later replays.  The replayed
+    learner is compared step by step with a twin that runs the same steps eagerly and makes the same interleaved calls."""
+    from pmx import actor_tower, mappo
+    assert mappo.PPOLearner.graph_replay_safe()
+    shape, B = (8, 11, 14), 512
+    torch.manual_seed(5)
+    a = mappo.MAPPOAgent(shape, 5, 2).cuda()
+    b = mappo.MAPPOAgent(shape, 5, 2).cuda()
+    b.load_state_dict(a.state_dict())
+    la, lb = mappo.PPOLearner(a, autocast_dtype=torch.bfloat16), mappo.PPOLearner(b, autocast_dtype=torch.bfloat16)
+    lb.capture(B, shape, torch.uint8, merged_batch=B // 2)
+    g = torch.Generator(device="cuda").manual_seed(6)
+    big = (torch.rand((6000,) + shape, device="cuda", generator=g) < 0.2).to(torch.uint8)
+    junk = []
+    for k in range(6):
+        obs = (torch.rand((B,) + shape, device="cuda", generator=g) < 0.2).to(torch.uint8)
+        mg = (torch.rand((B // 2,) + shape, device="cuda", generator=g) < 0.2).to(torch.uint8)
+        act = torch.randint(0, 5, (B,), device="cuda", generator=g)
+        logp = -1.6 + 0.05 * torch.randn(B, device="cuda", generator=g)
+        adv, ret = torch.randn(B, device="cuda", generator=g), torch.randn(B, device="cuda", generator=g)
+        sa = la.update_minibatch(obs, mg, act, logp, adv, ret)
+        sb = lb.update_minibatch_graph(obs, mg, act, logp, adv, ret)
+        assert torch.allclose(sa["loss"], sb["loss"], rtol=2e-3, atol=2e-4), (k, sa["loss"], sb["loss"])
+        assert torch.allclose(sa["grad_norm"], sb["grad_norm"], rtol=2e-2), (k, sa["grad_norm"], sb["grad_norm"])
+        # between replays: a larger inference call and a larger differentiated call through the same tower kernels, on both
+        # models, plus allocations that would land in any block the capture's scratch had given back
+        for m in (a, b):
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                m.logits(big)
+            feat = actor_tower.actor_tower(m.actor_backbone, big[:3000])
+            torch.autograd.grad(feat.float().square().mean(), actor_tower._tower_params(m.actor_backbone))
+        junk.append(torch.full((64 << 20,), float(k), device="cuda"))
+    cos = torch.nn.functional.cosine_similarity(la.bucket.data - la.ema, lb.bucket.data - lb.ema, dim=0)
+    assert float(cos) > 0.98, float(cos)
+    assert bool(torch.isfinite(lb.bucket.data).all())
+
+
 def test_flat_bf16_step_tracks_autocast_step():
     """PPOLearner.enable_bf16_flat (one flat bfloat16 weight copy, flat gradient) against the autocast step on the same data."""
     from pmx import mappo

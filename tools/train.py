@@ -23,7 +23,7 @@ ap.add_argument("--epochs", type=int, default=3)
 ap.add_argument("--updates", type=int, default=10)
 ap.add_argument("--total-updates", type=int, default=2000)
 ap.add_argument("--opponent", default="curriculum", choices=["random", "baseline", "self", "pool", "curriculum"])
-ap.add_argument("--obs", default="bfloat16")
+ap.add_argument("--obs", default=None, choices=["float32", "bfloat16", "uint8"], help="observation planes; default: the trainer's choice (uint8 under bf16 autocast, float32 otherwise)")
 ap.add_argument("--algorithm", default="mappo", choices=["mappo", "ippo"])
 ap.add_argument("--eval-every", type=int, default=0)
 ap.add_argument("--save", default="")

@@ -18,14 +18,19 @@ ap.add_argument("--minibatch", type=int, default=512)
 ap.add_argument("--epochs", type=int, default=3)
 ap.add_argument("--updates", type=int, default=2)
 ap.add_argument("--max-steps", type=int, default=0, help="cap optimizer steps per update (0 = all) for a quick probe")
-ap.add_argument("--obs", default="bfloat16")
+ap.add_argument("--obs", default=None, help="observation planes (default: the trainer's choice, uint8 under autocast)")
+ap.add_argument("--algorithm", default="mappo", choices=["mappo", "ippo"])
 ap.add_argument("--opponent", default="random")
 ap.add_argument("--no-autocast", action="store_true")
 args = ap.parse_args()
 
+import pmx
 from pmx import trainer
 
-tr = trainer.VecMAPPOTrainer(args.layout, args.envs, horizon=args.horizon, minibatch=args.minibatch, epochs=args.epochs,
+layout = args.layout
+if layout == "mazes":       # one generated 20x20 maze per env (BASELINE config 5)
+    layout = [pmx.Layout.from_text(pmx.maze_generator.generate_maze(s)) for s in range(1, args.envs + 1)]
+tr = trainer.VecMAPPOTrainer(layout, args.envs, algorithm=args.algorithm, horizon=args.horizon, minibatch=args.minibatch, epochs=args.epochs,
                              obs_dtype=args.obs, opponent=args.opponent, use_autocast=not args.no_autocast)
 sync = lambda: torch.cuda.synchronize()
 tr.rollout(); tr.compute_gae(); sync()          # warm-up (MIOpen find, allocator)
