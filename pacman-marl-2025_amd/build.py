@@ -17,6 +17,10 @@ HEADERS = ["pmx_device.h", os.path.join("..", "..", "include", "pmx.h")]
 # -ffp-contract=off: the float64 reward sums and the float32 GAE scan must round like the reference's Python/torch ops
 # (the network kernels opt back in per file with `#pragma clang fp contract(fast)`)
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+# per-file additions.  pmx_train.hip: MFMA results in ordinary VGPRs -- with accumulators placed in the AGPR half the one-pass
+# attention backward moved every dQ tile to a VGPR and back around each matrix instruction (24 v_accvgpr_* of ~70 vector
+# instructions per inner iteration on a kernel that is bound by its vector ALU)
+FILE_FLAGS = {"pmx_train.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def hipcc():
@@ -36,6 +40,7 @@ def source_hash():
     for d in _deps()[:-1]:
         with open(d, "rb") as f:
             h.update(f.read())
+    h.update(repr((CFLAGS, sorted(FILE_FLAGS.items()))).encode())       # a changed compiler flag is a changed library too
     return h.hexdigest()[:16]
 
 
@@ -68,7 +73,7 @@ def build(force=False, verbose=False):
                 src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s.replace(".hip", ".o"))
                 objs.append(obj)
                 if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
-                    cmd = [cc] + CFLAGS + ["-c", src, "-o", obj]
+                    cmd = [cc] + CFLAGS + FILE_FLAGS.get(s, []) + ["-c", src, "-o", obj]
                     if verbose:
                         print(" ".join(cmd))
                     jobs.append((s, subprocess.Popen(cmd, cwd=CSRC)))

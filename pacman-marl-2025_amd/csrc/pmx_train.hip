@@ -720,6 +720,135 @@ __global__ __launch_bounds__(512) void pmx_attn8_fwd_kernel(const __hip_bfloat16
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The forward kernel the product launches (pmx_attn8_fwd_kernel above is kept as the PMX_ATTN_FWD_V1 A/B reference).  The
+// kernel is bound by the vector ALU work of the softmax, so this version removes everything from the inner loop that is not
+// the exponential itself:
+//   * TWO passes over the keys per 16-query tile.  Pass 1 only finds each query's largest raw score (two matrix instructions and
+//     two v_maximum3_f32 per 32 keys; the matrix pipe is otherwise idle), so pass 2 exponentiates against a FIXED reference: no
+//     running maximum, no rescaling of the output tile, no cross-lane traffic inside the loop.  The reference enters pass 2 as the
+//     initial accumulator of the score product (s - m comes out of the matrix instruction), leaving exp2((s - m) c) = one
+//     multiply and one v_exp_f32 per score.
+//   * The row sum is a matrix product too: V^T is staged with a ninth row of ones, so row 8 of O^T accumulates the sum of the
+//     (bf16-rounded) probabilities that multiply V -- the normaliser is consistent with the numerator and costs no vector add.
+//   * Operands need no masks: lane groups 1..3 of an A operand fill k-slots 8..31, which meet the zeros of the B operand (the
+//     query row lives in group 0 only), so every lane simply reads its row (the four groups read the same 256 bytes: a broadcast).
+// Per 32 keys and lane: 8 multiplies, 8 exponentials, 4 packed conversions (the first kernel: ~75 vector instructions).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void pmx_attn8_fwd2_kernel(const __hip_bfloat16 *__restrict__ qkv, __hip_bfloat16 *__restrict__ out,
+                                                             float *__restrict__ lse, int S, int B, float scale, int bm)
+{
+    constexpr int D = 8, HEADS = 4, E = 32;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x, h = wave & 3, role = wave >> 2;        // two wavefronts per head: they split the query tiles
+    const int S_pad = (S + 31) & ~31;
+    // per head: K [S_pad][8] bf16, then V^T [9][S_pad] bf16 (row 8 = ones)
+    short *Ks = reinterpret_cast<short *>(smem) + (size_t)h * (D + 9) * S_pad;
+    short *Vt = Ks + (size_t)S_pad * D;
+    const short *base = reinterpret_cast<const short *>(qkv);
+    const size_t row_stride = bm ? (size_t)3 * E : (size_t)B * 3 * E;
+    const size_t head_off = (size_t)b * 3 * E * (bm ? S : 1) + (size_t)h * D;
+    const size_t out_row = bm ? (size_t)E : (size_t)B * E, out_off = (size_t)b * E * (bm ? S : 1) + (size_t)h * D;
+    for (int s = lane + 64 * role; s < S_pad; s += 128) {
+        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (s < S) {
+            kv = *reinterpret_cast<const uint4 *>(base + (size_t)s * row_stride + head_off + E);
+            vv = *reinterpret_cast<const uint4 *>(base + (size_t)s * row_stride + head_off + 2 * E);
+        }
+        *reinterpret_cast<uint4 *>(Ks + (size_t)s * D) = kv;
+        const short *vs = reinterpret_cast<const short *>(&vv);
+#pragma unroll
+        for (int d = 0; d < D; ++d) Vt[(size_t)d * S_pad + s] = vs[d];
+        Vt[(size_t)D * S_pad + s] = (short)0x3F80;                  // 1.0
+    }
+    __syncthreads();
+
+    const int g = lane >> 4, c = lane & 15;
+    const pmx_bf16x8 zero8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    const pmx_f32x4 z4 = { 0.f, 0.f, 0.f, 0.f };
+    const int n_qt = (S + 15) >> 4, n_kp = S_pad >> 5;
+    const float c2 = scale * 1.44269504088896341f;                  // raw score -> base-2 exponent
+    const short *krow = Ks + (size_t)c * D;                                              // + kp * 32 * D (+ 16 * D)
+    const short *vrow = Vt + (size_t)(c < D ? c : D) * S_pad + g * 4;                    // + kp * 32 (+ 16); rows >= 9 of the result are unused
+    const int last_lo = S - (n_kp - 1) * 32 - g * 4;               // key index r (resp. 16 + r) of the last pair is real iff r < last_lo (- 16)
+    for (int qt = role; qt < n_qt; qt += 2) {
+        const int q_row = qt * 16 + c;
+        pmx_bf16x8 qf = zero8;
+        if (g == 0 && q_row < S) qf = *reinterpret_cast<const pmx_bf16x8 *>(base + (size_t)q_row * row_stride + head_off);
+        // ---- pass 1: the largest raw score of each query (column c) --------------------------------------------------------
+        float mx = -3.0e38f;
+#pragma unroll 2
+        for (int kp = 0; kp < n_kp - 1; ++kp) {
+            const pmx_bf16x8 k0 = *reinterpret_cast<const pmx_bf16x8 *>(krow + (size_t)kp * 32 * D);
+            const pmx_bf16x8 k1 = *reinterpret_cast<const pmx_bf16x8 *>(krow + (size_t)(kp * 32 + 16) * D);
+            const pmx_f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf, z4, 0, 0, 0);
+            const pmx_f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf, z4, 0, 0, 0);
+            mx = __builtin_elementwise_maximum(__builtin_elementwise_maximum(s0[0], s0[1]), mx);
+            mx = __builtin_elementwise_maximum(__builtin_elementwise_maximum(s0[2], s0[3]), mx);
+            mx = __builtin_elementwise_maximum(__builtin_elementwise_maximum(s1[0], s1[1]), mx);
+            mx = __builtin_elementwise_maximum(__builtin_elementwise_maximum(s1[2], s1[3]), mx);
+        }
+        {   // the last pair may hold padded keys (zero K rows: score 0): they must not raise the reference
+            const int kp = n_kp - 1;
+            const pmx_bf16x8 k0 = *reinterpret_cast<const pmx_bf16x8 *>(krow + (size_t)kp * 32 * D);
+            const pmx_bf16x8 k1 = *reinterpret_cast<const pmx_bf16x8 *>(krow + (size_t)(kp * 32 + 16) * D);
+            const pmx_f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf, z4, 0, 0, 0);
+            const pmx_f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf, z4, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                mx = __builtin_elementwise_maximum(r < last_lo ? s0[r] : -3.0e38f, mx);
+                mx = __builtin_elementwise_maximum(r + 16 < last_lo ? s1[r] : -3.0e38f, mx);
+            }
+        }
+        mx = __builtin_elementwise_maximum(mx, __shfl_xor(mx, 16));
+        mx = __builtin_elementwise_maximum(mx, __shfl_xor(mx, 32));
+        // ---- pass 2: O^T (+ the row sums in row 8) against the fixed reference ---------------------------------------------
+        const pmx_f32x4 negm = { -mx, -mx, -mx, -mx };
+        pmx_f32x4 o = z4;
+        auto tile = [&](int kp, bool last) {
+            const pmx_bf16x8 k0 = *reinterpret_cast<const pmx_bf16x8 *>(krow + (size_t)kp * 32 * D);
+            const pmx_bf16x8 k1 = *reinterpret_cast<const pmx_bf16x8 *>(krow + (size_t)(kp * 32 + 16) * D);
+            const pmx_f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf, negm, 0, 0, 0);     // s - m
+            const pmx_f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf, negm, 0, 0, 0);
+            float e[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e[r] = __builtin_amdgcn_exp2f(s0[r] * c2);
+                e[4 + r] = __builtin_amdgcn_exp2f(s1[r] * c2);
+                if (last) {                                            // padded keys take no part
+                    if (r >= last_lo) e[r] = 0.f;
+                    if (r + 16 >= last_lo) e[4 + r] = 0.f;
+                }
+            }
+            pmx_bf16x8 pf;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) pf[r] = pmx_f2bf(e[r]);
+            // A = V^T (+ ones): row c, k-slot j -> key kp*32 + 4g + j (j < 4), kp*32 + 16 + 4g + (j-4): the order of pf's slots
+            const uint2 lo = *reinterpret_cast<const uint2 *>(vrow + kp * 32);
+            const uint2 hi = *reinterpret_cast<const uint2 *>(vrow + kp * 32 + 16);
+            const uint4 both = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const pmx_bf16x8 *>(&both), pf, o, 0, 0, 0);
+        };
+#pragma unroll 2
+        for (int kp = 0; kp < n_kp - 1; ++kp) tile(kp, false);
+        tile(n_kp - 1, true);
+        // O^T[row 4g + r][query c]: groups 0 and 1 hold d = 0..3 and 4..7, group 2 holds the row sums in r = 0
+        const float l = __shfl(o[0], 32 + c);
+        if (q_row < S) {
+            const float inv = 1.0f / l;
+            if (g < 2) {
+                short w4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w4[r] = pmx_f2bf(o[r] * inv);
+                *reinterpret_cast<uint2 *>(reinterpret_cast<short *>(out) + (size_t)q_row * out_row + out_off + g * 4) =
+                    *reinterpret_cast<const uint2 *>(w4);
+            }
+            if (g == 0 && lse) lse[((size_t)b * HEADS + h) * S + q_row] = (mx * c2 + __log2f(l)) * 0.69314718055994531f;   // natural log
+        }
+    }
+}
+
 // qkv_dev [S][B][96] bf16 (the packed in-projection of nn.MultiheadAttention with embed 32, 4 heads), out_dev [S][B][32]
 // bf16, lse_dev [B][4][S] float32 (log-sum-exp of the scaled scores per query; may be NULL).  batch_major: [B][S][.] instead.
 extern "C" int pmx_attn8_forward(const void *qkv_dev, void *out_dev, float *lse_dev, int32_t S, int32_t B, void *stream)
@@ -732,10 +861,23 @@ extern "C" int pmx_attn8_forward_layout(const void *qkv_dev, void *out_dev, floa
     if (B == 0) return PMX_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int S_pad = (S + 31) & ~31;
-    const size_t lds = (size_t)4 * 2 * S_pad * 8 * sizeof(short);
-    static bool attr_set_dev[64] = {};          // the attribute belongs to the function ON THE CURRENT DEVICE
     int cur_dev = 0;
     if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev < 0 || cur_dev >= 64) return PMX_ERR_HIP;
+    static const bool v1 = getenv("PMX_ATTN_FWD_V1") != nullptr;                    // A/B switch, read once
+    if (!v1) {
+        const size_t lds2 = (size_t)4 * (8 + 9) * S_pad * sizeof(short);
+        static bool attr2_dev[64] = {};
+        if (lds2 > 65536 && !attr2_dev[cur_dev]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(pmx_attn8_fwd2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return PMX_ERR_HIP;
+            attr2_dev[cur_dev] = true;
+        }
+        hipLaunchKernelGGL(pmx_attn8_fwd2_kernel, dim3(B), dim3(512), lds2, st, (const __hip_bfloat16 *)qkv_dev, (__hip_bfloat16 *)out_dev, lse_dev, S, B,
+                           0.35355339059327379f /* 1/sqrt(8) */, batch_major ? 1 : 0);
+        return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+    }
+    const size_t lds = (size_t)4 * 2 * S_pad * 8 * sizeof(short);
+    static bool attr_set_dev[64] = {};          // the attribute belongs to the function ON THE CURRENT DEVICE
     bool &attr_set = attr_set_dev[cur_dev];
     if (lds > 65536 && !attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(pmx_attn8_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -1003,32 +1145,43 @@ __global__ __launch_bounds__(512) void pmx_attn8_bwd_kernel(const __hip_bfloat16
 // dS^T[key][query] of dQ^T += K^T . dS^T, whose A operand is 8 consecutive keys of K^T per lane group straight from LDS.  dQ^T of
 // all ten query tiles stays in registers (40) across the key tiles.
 // ---------------------------------------------------------------------------------------------------------------
-template <int NPF>
-__global__ __launch_bounds__(256) void pmx_attn8_bwd_fused_kernel(const __hip_bfloat16 *__restrict__ qkv, const __hip_bfloat16 *__restrict__ outp,
-                                                                  const __hip_bfloat16 *__restrict__ dout, const float *__restrict__ lse,
-                                                                  __hip_bfloat16 *__restrict__ dqkv, int S, int B, float scale, int bm)
+// QS = 2 (sequences too long for one wave's registers: 416 padded tokens = the 20 x 20 boards): TWO wavefronts per (sample,
+// head) split the QUERY pairs -- each keeps the row operands and the dQ^T tiles of its own half (7 / 6 pairs: 168 registers) and
+// walks all key tiles; its dK / dV tiles then only cover its half of the queries, so after every key tile the second wave hands
+// its two tiles to the first through a double-buffered LDS slot (one block barrier per key tile), which adds them and stores.
+template <int NPF, int QS>
+__global__ __launch_bounds__(256 * QS) void pmx_attn8_bwd_fused_kernel(const __hip_bfloat16 *__restrict__ qkv, const __hip_bfloat16 *__restrict__ outp,
+                                                                       const __hip_bfloat16 *__restrict__ dout, const float *__restrict__ lse,
+                                                                       __hip_bfloat16 *__restrict__ dqkv, int S, int B, float scale, int bm)
 {
     constexpr int D = 8, HEADS = 4, E = 32, S_pad = 32 * NPF, TROW = 80;       // TROW: bytes per staging row (32 queries + pad)
+    constexpr int NQP = (NPF + QS - 1) / QS;                                   // query pairs per wave
+    constexpr int XCH = 2 * 2 * 16 * 16;                                       // bytes of one exchange slot: (dK, dV) x 2 lane groups x 16 keys x 4 floats
     extern __shared__ __align__(16) unsigned char smem[];
-    const int h = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int h = wave & 3, role = __builtin_amdgcn_readfirstlane(wave >> 2);
     const int b = blockIdx.x;
-    constexpr size_t per_wave = (size_t)3 * D * S_pad * sizeof(short) + (size_t)2 * S_pad * sizeof(float) + 32 * TROW;
-    unsigned char *mine = smem + (size_t)h * per_wave;
+    // QS > 1: the dO rows (A operands of the dP products) also sit in LDS, row-major, instead of in 8 NQP registers per wave
+    constexpr size_t per_head = (size_t)3 * D * S_pad * sizeof(short) + (size_t)2 * S_pad * sizeof(float) + (size_t)QS * 32 * TROW +
+                                (QS > 1 ? 2 * XCH + (size_t)S_pad * D * sizeof(short) : 0);
+    unsigned char *mine = smem + (size_t)h * per_head;
     short *Kt = reinterpret_cast<short *>(mine);                    // [8][S_pad]
     short *Qt = Kt + (size_t)D * S_pad;
     short *dOt = Qt + (size_t)D * S_pad;
     float *lse_s = reinterpret_cast<float *>(dOt + (size_t)D * S_pad);
     float *delta_s = lse_s + S_pad;
-    char *stg = reinterpret_cast<char *>(delta_s + S_pad);          // [32 rows = keys of the tile (16..31 stay zero)][32 queries] bf16
+    char *stg = reinterpret_cast<char *>(delta_s + S_pad) + (size_t)role * 32 * TROW;   // [32 rows = keys of the tile (16..31 stay zero)][32 queries] bf16, one per wave
+    unsigned char *xch = reinterpret_cast<unsigned char *>(delta_s + S_pad) + (size_t)QS * 32 * TROW;
+    short *dOr = reinterpret_cast<short *>(xch + 2 * XCH);          // [S_pad][8] (QS > 1 only)
     const short *base = reinterpret_cast<const short *>(qkv);
     const short *obase = reinterpret_cast<const short *>(outp);
     const short *dobase = reinterpret_cast<const short *>(dout);
     const size_t row_stride = bm ? (size_t)3 * E : (size_t)B * 3 * E, orow = bm ? (size_t)E : (size_t)B * E;
     const size_t head_off = (size_t)b * 3 * E * (bm ? S : 1) + (size_t)h * D, ohead = (size_t)b * E * (bm ? S : 1) + (size_t)h * D;
 
-    for (int s = lane; s < S_pad; s += 64) {
+    for (int s = lane + 64 * role; s < S_pad; s += 64 * QS) {
         uint4 qv = make_uint4(0, 0, 0, 0), kv = qv, dov = qv, ov = qv;
-        float ls = 1e30f;
+        float ls = 1e30f;                                           // padded queries: exp2(c (score - 1e30 / c)) = 0
         if (s < S) {
             qv = *reinterpret_cast<const uint4 *>(base + (size_t)s * row_stride + head_off);
             kv = *reinterpret_cast<const uint4 *>(base + (size_t)s * row_stride + head_off + E);
@@ -1046,11 +1199,18 @@ __global__ __launch_bounds__(256) void pmx_attn8_bwd_fused_kernel(const __hip_bf
             dOt[(size_t)d * S_pad + s] = d8[d];
             delta += __uint_as_float((uint32_t)(uint16_t)d8[d] << 16) * __uint_as_float((uint32_t)(uint16_t)o8[d] << 16);
         }
-        lse_s[s] = ls; delta_s[s] = delta;
+        if (QS > 1) *reinterpret_cast<uint4 *>(dOr + (size_t)s * D) = dov;
+        // Row constants as INITIAL ACCUMULATORS of the two score products: S' = Q K^T - lse / c comes out of the matrix instruction
+        // ready for p = exp2(c S') (a multiply and the exponential), dP' = dO V^T - delta ready for dS = p dP' (one multiply).
+        lse_s[s] = -ls / (scale * 1.44269504088896341f); delta_s[s] = -delta;
     }
     for (int i = lane; i < 32 * TROW / 4; i += 64) reinterpret_cast<uint32_t *>(stg)[i] = 0u;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // each head's LDS is private to its wavefront: no block barrier
-    __builtin_amdgcn_wave_barrier();
+    if (QS == 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // each head's LDS is private to its wavefront: no block barrier
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();                                            // the head's two waves staged half of the rows each
+    }
 
     const int g = lane >> 4, c = lane & 15;
     const pmx_bf16x8 zero8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -1073,14 +1233,18 @@ __global__ __launch_bounds__(256) void pmx_attn8_bwd_fused_kernel(const __hip_bf
         }
         return v;
     };
-    pmx_bf16x8 qr[2 * NPF], dr[2 * NPF];
-    pmx_f32x4 dq[2 * NPF];
+    const int qp0 = role * NQP;                                     // this wave's query pairs: qp0 .. qp0 + NQP - 1 (those < NPF)
+    pmx_bf16x8 qr[2 * NQP], dr[QS > 1 ? 1 : 2 * NQP];
+    pmx_f32x4 dq[2 * NQP];
 #pragma unroll
-    for (int t = 0; t < 2 * NPF; ++t) {
-        qr[t] = row8(base, row_stride, head_off, t * 16 + c);
-        dr[t] = row8(dobase, orow, ohead, t * 16 + c);
+    for (int t = 0; t < 2 * NQP; ++t) {
+        qr[t] = row8(base, row_stride, head_off, (2 * qp0 + t) * 16 + c);       // (rows past the sequence read as zero)
+        if (QS == 1) dr[t] = row8(dobase, orow, ohead, (2 * qp0 + t) * 16 + c);
         dq[t] = z4;
     }
+    // QS > 1: a dO row operand is one ds_read_b128 by EVERY lane (the four lane groups read the same 16 rows): the k-slots 8..31 it
+    // fills in groups 1..3 meet the zeros of the B operand (the V rows live in group 0 only), so they need no masking
+    const short *dOr_lane = dOr + (size_t)c * D;
     const int tr_row = (lane & 15) >> 2, tr_pc = lane & 3;
     for (int kt = 0; kt < n_t; ++kt) {
         const int k_row = kt * 16 + c;
@@ -1091,20 +1255,31 @@ __global__ __launch_bounds__(256) void pmx_attn8_bwd_fused_kernel(const __hip_bf
         if (c < D && g < 2) ka = *reinterpret_cast<const pmx_bf16x8 *>(Kt + (size_t)c * S_pad + kt * 16 + 8 * g);
         pmx_f32x4 dk = z4, dv = z4;
 #pragma unroll
-        for (int qp = 0; qp < NPF; ++qp) {
-            const pmx_f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[2 * qp], kf, z4, 0, 0, 0);
-            const pmx_f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[2 * qp + 1], kf, z4, 0, 0, 0);
-            const pmx_f32x4 p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dr[2 * qp], vf, z4, 0, 0, 0);
-            const pmx_f32x4 p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dr[2 * qp + 1], vf, z4, 0, 0, 0);
+        for (int j = 0; j < NQP; ++j) {
+            const int qp = qp0 + j;
+            if (QS > 1 && qp >= NPF) continue;                      // wave-uniform: the last wave may own one pair less
+            // (accumulator row r of lane group g is query 32 qp + 4 g + r, resp. + 16: four consecutive floats each)
+            const pmx_f32x4 nl0 = *reinterpret_cast<const pmx_f32x4 *>(lse_s + qp * 32 + g * 4), nl1 = *reinterpret_cast<const pmx_f32x4 *>(lse_s + qp * 32 + 16 + g * 4);
+            const pmx_f32x4 nd0 = *reinterpret_cast<const pmx_f32x4 *>(delta_s + qp * 32 + g * 4), nd1 = *reinterpret_cast<const pmx_f32x4 *>(delta_s + qp * 32 + 16 + g * 4);
+            const pmx_f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[2 * j], kf, nl0, 0, 0, 0);
+            const pmx_f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[2 * j + 1], kf, nl1, 0, 0, 0);
+            pmx_bf16x8 d0, d1;
+            if (QS > 1) {
+                d0 = *reinterpret_cast<const pmx_bf16x8 *>(dOr_lane + (size_t)(qp * 32) * D);
+                d1 = *reinterpret_cast<const pmx_bf16x8 *>(dOr_lane + (size_t)(qp * 32 + 16) * D);
+            } else {
+                d0 = dr[2 * j], d1 = dr[2 * j + 1];
+            }
+            const pmx_f32x4 p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0, vf, nd0, 0, 0, 0);
+            const pmx_f32x4 p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1, vf, nd1, 0, 0, 0);
             pmx_bf16x8 pf, dsf;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int qa = qp * 32 + g * 4 + r, qb = qa + 16;
-                const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c2, -lse_s[qa]));
-                const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c2, -lse_s[qb]));
+                const float e0 = __builtin_amdgcn_exp2f(s0[r] * c2);
+                const float e1 = __builtin_amdgcn_exp2f(s1[r] * c2);
                 pf[r] = pmx_f2bf(e0); pf[4 + r] = pmx_f2bf(e1);
-                dsf[r] = pmx_f2bf(e0 * (p0[r] - delta_s[qa]));
-                dsf[4 + r] = pmx_f2bf(e1 * (p1[r] - delta_s[qb]));
+                dsf[r] = pmx_f2bf(e0 * p0[r]);
+                dsf[4 + r] = pmx_f2bf(e1 * p1[r]);
             }
             dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(dOt, qp), pf, dv, 0, 0, 0);
             dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Qt, qp), dsf, dk, 0, 0, 0);
@@ -1123,12 +1298,29 @@ __global__ __launch_bounds__(256) void pmx_attn8_bwd_fused_kernel(const __hip_bf
                 const pmx_bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pmx_bf16x4 __attribute__((address_space(3))) *)(a0));
                 const pmx_bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pmx_bf16x4 __attribute__((address_space(3))) *)(a0 + 4 * TROW));
                 const pmx_bf16x8 bT = { lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3] };
-                dq[2 * qp + half] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, bT, dq[2 * qp + half], 0, 0, 0);
+                dq[2 * j + half] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, bT, dq[2 * j + half], 0, 0, 0);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the staging rows are rewritten by the next pair
             __builtin_amdgcn_wave_barrier();
         }
-        if (k_row < S && g < 2) {
+        if (QS > 1) {
+            // the second wave's partial dK^T / dV^T tiles (its half of the queries) -> slot kt & 1; the first wave adds them after the
+            // barrier.  Double-buffered: the slot written for tile kt + 1 is not the one being read for tile kt, and the slot of
+            // tile kt + 2 is written only after barrier kt + 1, which the reader reaches after its reads of tile kt.
+            float *slot = reinterpret_cast<float *>(xch + (size_t)(kt & 1) * XCH);
+            if (role == 1 && g < 2) {
+                *reinterpret_cast<pmx_f32x4 *>(slot + ((0 * 2 + g) * 16 + c) * 4) = dk;
+                *reinterpret_cast<pmx_f32x4 *>(slot + ((1 * 2 + g) * 16 + c) * 4) = dv;
+            }
+            __syncthreads();
+            if (role == 0 && g < 2) {
+                const pmx_f32x4 a = *reinterpret_cast<const pmx_f32x4 *>(slot + ((0 * 2 + g) * 16 + c) * 4);
+                const pmx_f32x4 e = *reinterpret_cast<const pmx_f32x4 *>(slot + ((1 * 2 + g) * 16 + c) * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { dk[r] += a[r]; dv[r] += e[r]; }
+            }
+        }
+        if (role == 0 && k_row < S && g < 2) {
             short wk[4], wv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { wk[r] = pmx_f2bf(dk[r] * scale); wv[r] = pmx_f2bf(dv[r]); }
@@ -1137,8 +1329,8 @@ __global__ __launch_bounds__(256) void pmx_attn8_bwd_fused_kernel(const __hip_bf
         }
     }
 #pragma unroll
-    for (int t = 0; t < 2 * NPF; ++t) {
-        const int q_row = t * 16 + c;
+    for (int t = 0; t < 2 * NQP; ++t) {
+        const int q_row = (2 * qp0 + t) * 16 + c;
         if (q_row < S && g < 2) {
             short w4[4];
 #pragma unroll
@@ -1176,7 +1368,21 @@ extern "C" int pmx_attn8_backward_layout(const void *qkv_dev, const void *out_de
     if (S_pad == 160 && !generic_only && !two_pass) {
         // one pass, one wavefront per (sample, head): 4 x (3 x 8 x 160 x 2 + 2 x 160 x 4 + 32 x 80) = 45 KB of LDS
         constexpr size_t lds_f = (size_t)4 * ((size_t)3 * 8 * 160 * sizeof(short) + (size_t)2 * 160 * sizeof(float) + 32 * 80);
-        hipLaunchKernelGGL(pmx_attn8_bwd_fused_kernel<5>, dim3(B), dim3(256), lds_f, st, (const __hip_bfloat16 *)qkv_dev, (const __hip_bfloat16 *)out_dev,
+        hipLaunchKernelGGL((pmx_attn8_bwd_fused_kernel<5, 1>), dim3(B), dim3(256), lds_f, st, (const __hip_bfloat16 *)qkv_dev, (const __hip_bfloat16 *)out_dev,
+                           (const __hip_bfloat16 *)dout_dev, lse_dev, (__hip_bfloat16 *)dqkv_dev, S, B, 0.35355339059327379f, batch_major ? 1 : 0);
+        return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+    }
+    if (S_pad == 416 && !generic_only && !two_pass) {
+        // one pass, two wavefronts per (sample, head) splitting the query pairs (the 20 x 20 boards: 400 tokens):
+        // 4 x (4 x 8 x 416 x 2 + 2 x 416 x 4 + 2 x 32 x 80 + 2 x 1 024) = 145 KB of LDS, one block of eight waves per CU
+        constexpr size_t lds_f = (size_t)4 * ((size_t)4 * 8 * 416 * sizeof(short) + (size_t)2 * 416 * sizeof(float) + 2 * 32 * 80 + 2 * 1024);
+        static bool attr2_dev[64] = {};
+        if (!attr2_dev[cur_dev]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(pmx_attn8_bwd_fused_kernel<13, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return PMX_ERR_HIP;
+            attr2_dev[cur_dev] = true;
+        }
+        hipLaunchKernelGGL((pmx_attn8_bwd_fused_kernel<13, 2>), dim3(B), dim3(512), lds_f, st, (const __hip_bfloat16 *)qkv_dev, (const __hip_bfloat16 *)out_dev,
                            (const __hip_bfloat16 *)dout_dev, lse_dev, (__hip_bfloat16 *)dqkv_dev, S, B, 0.35355339059327379f, batch_major ? 1 : 0);
         return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
     }

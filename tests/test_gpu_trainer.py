@@ -322,7 +322,7 @@ def test_fused_groupnorm_gelu_matches_torch(dtype, tol, hw, cl):
             assert float((u - v).abs().max()) <= tol * scale * mult, (name, with_res, float((u - v).abs().max()), scale)
 
 
-@pytest.mark.parametrize("S,B", [(154, 37), (140, 5), (400, 9), (33, 3), (1024, 2)])
+@pytest.mark.parametrize("S,B", [(154, 37), (140, 5), (400, 9), (33, 3), (1024, 2), (160, 3), (1, 2), (17, 1)])
 def test_mfma_attention_forward_matches_torch(S, B):
     """pmx_attn8_forward against softmax(q k^T / sqrt(8)) v computed by torch in float32 from the same bf16 inputs.
     Random (asymmetric) data: a transposed or permuted fragment layout cannot pass."""
@@ -339,7 +339,28 @@ def test_mfma_attention_forward_matches_torch(S, B):
     assert float((lse - torch.logsumexp(sc, -1)).abs().max()) <= 2e-3
 
 
-@pytest.mark.parametrize("S,B", [(154, 19), (140, 5), (400, 4), (33, 3), (640, 2)])
+def test_mfma_attention_forward_with_large_and_shifted_scores():
+    """The forward kernel exponentiates against each query's exact largest raw score (found in a first pass over the keys): scores
+    of +-50 .. 300 and rows whose scores are ALL far below zero (a common component in every key, as an in-projection bias produces)
+    must neither overflow nor underflow."""
+    from pmx import mappo
+    torch.manual_seed(77)
+    S, B = 154, 6
+    x = torch.randn(S, B, 96, device="cuda") * 4.0
+    x[:, :, 32:64] += -25.0 * torch.sign(x[:1, :, 0:32])           # every key carries a large component opposed to the FIRST query's signs
+    qkv = x.to(torch.bfloat16)
+    out, lse = mappo.attention8_forward(qkv, want_lse=True)
+    q, k, v = qkv.float().chunk(3, dim=-1)
+    q, k, v = (t.reshape(S, B, 4, 8).permute(1, 2, 0, 3) for t in (q, k, v))
+    sc = torch.matmul(q, k.transpose(-1, -2)) / 8 ** 0.5
+    assert float(sc[:, :, 0].max()) < -50.0 and float(sc.max()) > 50.0         # rows far below zero and rows far above exist
+    ref = torch.matmul(torch.softmax(sc, -1), v).permute(2, 0, 1, 3).reshape(S, B, 32)
+    assert bool(torch.isfinite(out.float()).all()) and bool(torch.isfinite(lse).all())
+    assert float((out.float() - ref).abs().max()) <= 2e-2 * (float(ref.abs().max()) + 1e-6)
+    assert float(((lse - torch.logsumexp(sc, -1)).abs() / (1.0 + torch.logsumexp(sc, -1).abs())).max()) <= 2e-3
+
+
+@pytest.mark.parametrize("S,B", [(154, 19), (140, 5), (400, 4), (33, 3), (640, 2), (397, 3)])
 def test_mfma_attention_backward_matches_torch(S, B):
     """pmx_attn8_backward against torch autograd of softmax(q k^T / sqrt(8)) v in float32 on the same bf16 inputs."""
     from pmx import mappo
