@@ -208,14 +208,16 @@ int pmx_profile_end(pmx_env *env, double *rule_ms, int32_t *rule_launches, doubl
 int pmx_gae(const float *rewards_dev, const float *values_dev, const float *dones_dev, const float *last_value_dev,
             int32_t T, int32_t n, double gamma, double lam, float *adv_dev, float *ret_dev, void *stream);
 
-/* Training-side observation post-processing on [n][8][H][W] blocks of obs_dtype elements
- * (pacman_mappo_resnet.py:215-229 canonicalize_obs for a red learner, :267-274 merge_obs_for_critic). */
 /* Column sums of a [rows][C] bfloat16 matrix as PMX_COLSUM_BLOCKS partial rows of float32 (the caller adds them): the
  * bias gradients `grad_output.sum((0, 1))` of the token linears in the critic's encoder layers (nn.TransformerEncoderLayer
  * backward, pacman_mappo_resnet.py:138-141).  C a multiple of 8, at most 256. */
 #define PMX_COLSUM_BLOCKS 512
 int pmx_colsum_bf16(const void *x_dev, int64_t rows, int32_t C, float *partial_dev, void *stream);
 
+/* Training-side observation post-processing on [n][8][H][W] blocks of obs_dtype elements, for callers that take the four
+ * observations of pmx_step and post-process them the way the reference script does (pacman_mappo_resnet.py:215-229
+ * canonicalize_obs for a red learner, :267-274 merge_obs_for_critic): pmx.trainer.canonicalize_obs / merge_obs on device
+ * tensors.  (The training loop itself gets both from pmx_emit_team_obs, already written into its rollout buffers.) */
 int pmx_canonicalize_obs(const void *in_dev, void *out_dev, int32_t n, int32_t H, int32_t W, int32_t obs_dtype,
                          void *stream);
 int pmx_merge_obs(const void *a_dev, const void *b_dev, void *out_dev, int32_t n, int32_t H, int32_t W,

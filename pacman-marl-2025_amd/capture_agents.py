@@ -22,25 +22,6 @@ def manhattanDistance(a, b):                                        # util.py:20
     return abs(a[0] - b[0]) + abs(a[1] - b[1])
 
 
-class Counter(dict):
-    """The slice of util.Counter (util.py:215-425) the reflex bots use: default 0 and the dot product."""
-
-    def __getitem__(self, k):
-        self.setdefault(k, 0)
-        return dict.__getitem__(self, k)
-
-    def __mul__(self, y):                                           # util.py:363-385
-        total = 0
-        x = self
-        if len(x) > len(y):
-            x, y = y, x
-        for key in x:
-            if key not in y:
-                continue
-            total += x[key] * y[key]
-        return total
-
-
 class Distancer:
     """distanceCalculator.Distancer (distanceCalculator.py:24-75): all-pairs maze distances of a layout."""
 

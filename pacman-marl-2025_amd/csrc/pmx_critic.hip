@@ -14,7 +14,8 @@
 // Backward recomputes the forward from x (nothing is saved), runs LayerNorm's and the two products' input gradients the same
 // way (dH = W2^T dF, dX = W1^T dH + dz) and forms the weight gradients -- contractions over TOKENS -- from a 32-token
 // staging area in LDS read back through ds_read_b64_tr_b16; their 32 output tiles (128 accumulator registers) stay in
-// registers across all tiles of the wave and leave through one block-level LDS sum + float atomics.
+// registers across all tiles of the wave and leave through one block-level LDS sum into the block's partial row (plain
+// stores; a row-sum kernel adds the rows).
 #pragma clang fp contract(fast)
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>

@@ -1223,15 +1223,19 @@ __global__ __launch_bounds__(256 * QS) void pmx_attn8_bwd_fused_kernel(const __h
         if (g == 0 && r < S) v = *reinterpret_cast<const pmx_bf16x8 *>(src + (size_t)r * stride + off);
         return v;
     };
+    // A fragment [row d][k-slot j] of a transposed array: rows 8..15 of the operand only feed rows 8..15 of the product, which
+    // nobody reads, so those lanes simply repeat rows 0..7 (no exec mask, no zero fill in the loop)
     auto tfrag = [&](const short *T, int pair) -> pmx_bf16x8 {
-        pmx_bf16x8 v = zero8;
-        if (c < D) {
-            const short *p = T + (size_t)c * S_pad + pair * 32 + g * 4;
-            const uint2 lo = *reinterpret_cast<const uint2 *>(p), hi = *reinterpret_cast<const uint2 *>(p + 16);
-            const uint4 both = make_uint4(lo.x, lo.y, hi.x, hi.y);
-            v = *reinterpret_cast<const pmx_bf16x8 *>(&both);
-        }
-        return v;
+        const short *p = T + (size_t)(c & (D - 1)) * S_pad + pair * 32 + g * 4;
+        const uint2 lo = *reinterpret_cast<const uint2 *>(p), hi = *reinterpret_cast<const uint2 *>(p + 16);
+        const uint4 both = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        return *reinterpret_cast<const pmx_bf16x8 *>(&both);
+    };
+    auto pack2bf = [](float x, float y) -> uint32_t {             // one v_cvt_pk_bf16_f32
+        typedef __attribute__((ext_vector_type(2))) float f2;
+        typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+        const f2 f = {x, y};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, b2));
     };
     const int qp0 = role * NQP;                                     // this wave's query pairs: qp0 .. qp0 + NQP - 1 (those < NPF)
     pmx_bf16x8 qr[2 * NQP], dr[QS > 1 ? 1 : 2 * NQP];
@@ -1257,7 +1261,8 @@ __global__ __launch_bounds__(256 * QS) void pmx_attn8_bwd_fused_kernel(const __h
 #pragma unroll
         for (int j = 0; j < NQP; ++j) {
             const int qp = qp0 + j;
-            if (QS > 1 && qp >= NPF) continue;                      // wave-uniform: the last wave may own one pair less
+            if (QS > 1 && NQP * QS > NPF && j == NQP - 1 && qp >= NPF) continue;   // wave-uniform: the last wave owns one pair less (only ITS last
+                                                                                    // step is conditional, so the others form one scheduling region)
             // (accumulator row r of lane group g is query 32 qp + 4 g + r, resp. + 16: four consecutive floats each)
             const pmx_f32x4 nl0 = *reinterpret_cast<const pmx_f32x4 *>(lse_s + qp * 32 + g * 4), nl1 = *reinterpret_cast<const pmx_f32x4 *>(lse_s + qp * 32 + 16 + g * 4);
             const pmx_f32x4 nd0 = *reinterpret_cast<const pmx_f32x4 *>(delta_s + qp * 32 + g * 4), nd1 = *reinterpret_cast<const pmx_f32x4 *>(delta_s + qp * 32 + 16 + g * 4);
@@ -1272,26 +1277,26 @@ __global__ __launch_bounds__(256 * QS) void pmx_attn8_bwd_fused_kernel(const __h
             }
             const pmx_f32x4 p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0, vf, nd0, 0, 0, 0);
             const pmx_f32x4 p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1, vf, nd1, 0, 0, 0);
-            pmx_bf16x8 pf, dsf;
+            float e0[4], e1[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e0 = __builtin_amdgcn_exp2f(s0[r] * c2);
-                const float e1 = __builtin_amdgcn_exp2f(s1[r] * c2);
-                pf[r] = pmx_f2bf(e0); pf[4 + r] = pmx_f2bf(e1);
-                dsf[r] = pmx_f2bf(e0 * p0[r]);
-                dsf[4 + r] = pmx_f2bf(e1 * p1[r]);
+                e0[r] = __builtin_amdgcn_exp2f(s0[r] * c2);
+                e1[r] = __builtin_amdgcn_exp2f(s1[r] * c2);
             }
+            // probabilities and dS as bf16 pairs: slots 0..3 = queries 4g + r of the first tile of the pair, 4..7 = of the second
+            const uint4 pw = make_uint4(pack2bf(e0[0], e0[1]), pack2bf(e0[2], e0[3]), pack2bf(e1[0], e1[1]), pack2bf(e1[2], e1[3]));
+            const uint4 dw = make_uint4(pack2bf(e0[0] * p0[0], e0[1] * p0[1]), pack2bf(e0[2] * p0[2], e0[3] * p0[3]),
+                                        pack2bf(e1[0] * p1[0], e1[1] * p1[1]), pack2bf(e1[2] * p1[2], e1[3] * p1[3]));
+            const pmx_bf16x8 pf = *reinterpret_cast<const pmx_bf16x8 *>(&pw), dsf = *reinterpret_cast<const pmx_bf16x8 *>(&dw);
             dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(dOt, qp), pf, dv, 0, 0, 0);
             dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Qt, qp), dsf, dk, 0, 0, 0);
             // dS of the tile as [key c][queries 4g .. 4g+3 | 16 + 4g ..] -> staging rows 0..15 (a padded key's column holds whatever
-            // the zero K row produced; its K^T entries in `ka` are zero, so it adds nothing)
-            {
-                const uint4 w = *reinterpret_cast<const uint4 *>(&dsf);
-                *reinterpret_cast<uint2 *>(stg + c * TROW + (4 * g) * 2) = make_uint2(w.x, w.y);
-                *reinterpret_cast<uint2 *>(stg + c * TROW + (16 + 4 * g) * 2) = make_uint2(w.z, w.w);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            // the zero K row produced; its K^T entries in `ka` are zero, so it adds nothing).  The write, the transposing reads below
+            // and the next pair's write are LDS operations of ONE wave on one array: the hardware runs them in program order and
+            // the compiler keeps may-aliasing accesses in order, so nothing else separates them (a fence here also pinned the next
+            // pair's operand reads behind this pair's reads).
+            *reinterpret_cast<uint2 *>(stg + c * TROW + (4 * g) * 2) = make_uint2(dw.x, dw.y);
+            *reinterpret_cast<uint2 *>(stg + c * TROW + (16 + 4 * g) * 2) = make_uint2(dw.z, dw.w);
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const char *a0 = stg + (8 * g + tr_row) * TROW + half * 32 + tr_pc * 8;
@@ -1300,8 +1305,6 @@ __global__ __launch_bounds__(256 * QS) void pmx_attn8_bwd_fused_kernel(const __h
                 const pmx_bf16x8 bT = { lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3] };
                 dq[2 * j + half] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, bT, dq[2 * j + half], 0, 0, 0);
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the staging rows are rewritten by the next pair
-            __builtin_amdgcn_wave_barrier();
         }
         if (QS > 1) {
             // the second wave's partial dK^T / dV^T tiles (its half of the queries) -> slot kt & 1; the first wave adds them after the

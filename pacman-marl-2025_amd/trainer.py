@@ -39,8 +39,23 @@ def shaping_from_agent_words(prev, cur):
     return out
 
 
+_OBS_CODES = {torch.float32: _lib.OBS_F32, torch.bfloat16: _lib.OBS_BF16, torch.uint8: _lib.OBS_U8}
+
+
+def _plane_kernel_ok(*ts):
+    return all(t.is_cuda and t.dim() == 4 and t.shape[1] == 8 and t.dtype in _OBS_CODES and t.dtype == ts[0].dtype for t in ts)
+
+
 def merge_obs(a, b):
-    """merge_obs_for_critic (pacman_mappo_resnet.py:267-274) on batches [N,8,H,W]."""
+    """merge_obs_for_critic (pacman_mappo_resnet.py:267-274) on batches [N,8,H,W]: pmx_merge_obs on device tensors of an
+    observation dtype, the torch formulation otherwise."""
+    if _plane_kernel_ok(a, b) and a.shape == b.shape:
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty_like(a)
+        st = C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+        _lib.check(_lib.load().pmx_merge_obs(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.shape[0], a.shape[2], a.shape[3],
+                                             _OBS_CODES[a.dtype], st), "pmx_merge_obs")
+        return out
     m = a.clone()
     m[:, 1] = torch.maximum(torch.maximum(a[:, 1], b[:, 1]), torch.zeros_like(a[:, 1]))
     m[:, 4] = 0
@@ -48,7 +63,15 @@ def merge_obs(a, b):
 
 
 def canonicalize_obs(o):
-    """canonicalize_obs for a red learner (pacman_mappo_resnet.py:215-229): flip x, swap planes 2<->3, 6<->7."""
+    """canonicalize_obs for a red learner (pacman_mappo_resnet.py:215-229): flip x, swap planes 2<->3, 6<->7; pmx_canonicalize_obs
+    on device tensors [N,8,H,W] of an observation dtype, the torch formulation otherwise."""
+    if _plane_kernel_ok(o):
+        o = o.contiguous()
+        out = torch.empty_like(o)
+        st = C.c_void_p(torch.cuda.current_stream(o.device).cuda_stream)
+        _lib.check(_lib.load().pmx_canonicalize_obs(o.data_ptr(), out.data_ptr(), o.shape[0], o.shape[2], o.shape[3],
+                                                    _OBS_CODES[o.dtype], st), "pmx_canonicalize_obs")
+        return out
     return torch.flip(o, dims=[-1])[..., [0, 1, 3, 2, 4, 5, 7, 6], :, :]
 
 

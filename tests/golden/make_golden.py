@@ -9,7 +9,7 @@ as small .npz/.json data files.  Those files are what pins the oracle
 
 Usage (from anywhere):
     PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python tests/golden/make_golden.py [section ...]
-sections: traj scen dist maze gae ppo shaping bots   (default: all)
+sections: traj scen dist maze gae ppo ppo_init shaping bots   (default: all)
 
 Fixture catalogue:
   G1 traj_*.npz      gymPacMan_parallel_env(self_play=True) trajectories, per sub-step state
@@ -19,6 +19,7 @@ Fixture catalogue:
   G5 mazes.json      mazeGenerator.generateMaze(seed) text
   G6 gae.npz         pacman_mappo_resnet.compute_gae
   G7 ppo.npz         MAPPOAgent forward / PPO loss / grad-norm / Adam step with closed-form weights
+  G7b ppo_init.npz   the same on the reference's own (seeded) orthogonal initialisation, paired rows: pins the bf16 production path
   G8 shaping.npz     compute_heuristic_shaping / canonicalize_obs / merge_obs_for_critic
   G9 bots_*.json     baselineTeam / randomTeam action traces under random.seed(k)
 """
@@ -721,6 +722,84 @@ def section_ppo():
     print(f"  ppo.npz loss={loss.item():.6f} pg={pg.item():.6f} vl={vl.item():.6f} gn={float(gn):.6f}")
 
 
+def sharpen_init(model):
+    """A deterministic transform of an initialised MAPPOAgent that both sides can apply (tests/test_mappo_cpu.py has the same
+    function): the reference's init makes near-uniform policies (last actor layer: gain 0.01) and near-constant values, which pin
+    little; scaled up, logits and values spread over O(1) while every weight is still the seeded orthogonal draw."""
+    with torch.no_grad():
+        model.actor_head[3].weight.mul_(120.0)
+        model.critic_head[2].weight.mul_(6.0)
+        model.critic_projector[0].weight.mul_(2.5)
+        for j, (name, p) in enumerate(model.named_parameters()):
+            if p.dim() == 1 and name.endswith("bias"):
+                p.add_(0.1 * torch.sin(0.37 * torch.arange(p.numel(), dtype=torch.float64) + 1.3 * j).to(p.dtype))
+
+
+def section_ppo_init():
+    """G7b: the reference's MAPPOAgent with ITS OWN initialisation (orthogonal weights, pacman_mappo_resnet.py:149-158) under a
+    fixed torch seed -- the seed and per-tensor checksums are stored, not the 2.6 M weights -- on 32 env-ticks x 2 learners of a
+    real trajectory (paired rows 2k, 2k + 1 share merged input k), once as initialised ("init") and once after sharpen_init
+    ("sharp": logits and values of O(1)).  Unlike the closed-form sine weights of G7, these are the weights training starts
+    from, so a bf16 evaluation of this fixture is representative of the production path."""
+    print("G7b PPO losses, reference initialisation")
+    with contextlib.redirect_stdout(io.StringIO()):
+        import pacman_mappo_resnet as M
+    seed = 20260
+    torch.set_num_threads(1)
+    z = np.load(os.path.join(OUT, "traj_small_hunter.npz"))
+    obs_all = z["obs"]  # [T,4,8,H,W] u8
+    P = 32
+    idx = np.arange(7, 7 + P * 9, 9)
+    ob1 = torch.tensor(obs_all[idx, 1].astype(np.float32))
+    ob3 = torch.tensor(obs_all[idx, 3].astype(np.float32))
+    obs = torch.stack([ob1, ob3], dim=1).reshape((2 * P,) + tuple(ob1.shape[1:]))              # rows 2k, 2k+1 = the two blue learners
+    merged = torch.stack([M.merge_obs_for_critic([ob1[i], ob3[i]]) for i in range(P)])           # [P]
+    clip_eps, ent_coef, lr = M.CLIP_EPS, 0.02, 2e-4
+    out = dict(obs=obs.numpy().astype(np.uint8), merged=merged.numpy().astype(np.uint8))
+    names = None
+    for tag in ("init", "sharp"):
+        torch.manual_seed(seed)
+        model = M.MAPPOAgent(tuple(obs.shape[1:]), 5, 2)
+        if tag == "sharp":
+            sharpen_init(model)
+        names = [n for n, _ in model.named_parameters()]
+        rng = np.random.RandomState(11)
+        with torch.no_grad():
+            logits0 = model.actor_head(model.actor_backbone(obs))
+            lp0 = torch.log_softmax(logits0, -1)
+        act = torch.tensor(rng.randint(5, size=2 * P), dtype=torch.long)
+        old_logp = (lp0.gather(1, act.view(-1, 1)).squeeze(1) + torch.tensor((0.05 * rng.randn(2 * P)).astype(np.float32)))
+        adv = torch.tensor(rng.randn(2 * P).astype(np.float32))
+        ret = torch.tensor((0.5 * rng.randn(2 * P)).astype(np.float32))
+        sums = [float(p.detach().double().sum()) for p in model.parameters()]
+        abss = [float(p.detach().double().abs().sum()) for p in model.parameters()]
+        vals, lps, ent = model.evaluate(obs, merged.repeat_interleave(2, dim=0), act)           # :556-557 expands the merged input per agent
+        norm_adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+        ratio = (lps - old_logp).exp()
+        pg = -torch.min(norm_adv * ratio, norm_adv * torch.clamp(ratio, 1 - clip_eps, 1 + clip_eps)).mean()
+        vl = 0.5 * ((vals - ret) ** 2).mean()
+        loss = pg + M.VF_COEF * vl - ent_coef * ent.mean()
+        model.zero_grad()
+        loss.backward()
+        gnorms = [float(p.grad.double().norm()) for p in model.parameters()]
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), M.MAX_GRAD_NORM)
+        rec = dict(act=act.numpy(), old_logp=old_logp.numpy(), adv=adv.numpy(), ret=ret.numpy(), logits=logits0.numpy(),
+                   values=vals.detach().numpy(), logp=lps.detach().numpy(), entropy=ent.detach().numpy(),
+                   pg=np.float32(pg.item()), vl=np.float32(vl.item()), loss=np.float32(loss.item()), grad_norm=np.float32(float(gn)),
+                   param_sum=np.array(sums, np.float64), param_abs=np.array(abss, np.float64), grad_norms=np.array(gnorms, np.float64))
+        out.update({f"{tag}_{k}": v for k, v in rec.items()})
+        print(f"  {tag}: loss={loss.item():.6f} pg={pg.item():.6f} vl={vl.item():.6f} gn={float(gn):.6f} "
+              f"|logits|max={float(logits0.abs().max()):.4f} values in [{float(vals.min()):.3f}, {float(vals.max()):.3f}] "
+              f"entropy mean {float(ent.mean()):.4f}")
+    out["meta"] = np.frombuffer(json.dumps(dict(
+        seed=seed, clip_eps=clip_eps, ent_coef=ent_coef, lr=lr, vf_coef=M.VF_COEF, max_grad_norm=M.MAX_GRAD_NORM,
+        weights="torch.manual_seed(seed); MAPPOAgent(obs_shape, 5, 2): the reference's orthogonal initialisation; 'sharp' = sharpen_init of it",
+        param_names=names, torch_version=torch.__version__,
+        source="pacman_mappo_resnet.MAPPOAgent.__init__/evaluate + PPO loss lines 577-590")).encode(), np.uint8)
+    np.savez_compressed(os.path.join(OUT, "ppo_init.npz"), **out)
+    print("  ppo_init.npz")
+
+
 def section_shaping():
     print("G8 shaping / canonicalize / merge")
     with contextlib.redirect_stdout(io.StringIO()):
@@ -803,7 +882,7 @@ def section_bots():
 
 
 SECTIONS = dict(traj=section_traj, scen=section_scen, dist=section_dist, maze=section_maze, gae=section_gae,
-                ppo=section_ppo, shaping=section_shaping, bots=section_bots)
+                ppo=section_ppo, ppo_init=section_ppo_init, shaping=section_shaping, bots=section_bots)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)

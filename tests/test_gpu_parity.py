@@ -274,9 +274,10 @@ def test_invalid_layouts_raise():
 
 
 # --------------------------------------------------------------------------------- full-size, size-independent
-@pytest.mark.parametrize("layname,N", [("smallCapture", 16384), ("tinyCapture", 4096)])
+@pytest.mark.parametrize("layname,N", [("smallCapture", 16384), ("tinyCapture", 4096), ("smallCapture", 8192)])
 def test_full_size_properties(layname, N):
-    """BASELINE.json sizes.  Properties that need no reference at that size:
+    """BASELINE.json sizes (configs 3 and 2, and the 8 192-env per-GPU shard of config 4).  Properties that need no reference at
+    that size:
        replication (the same action stream in every 64-env tile gives identical results), pellet conservation
        (food on board + carried + returned == layout total), and observation/state consistency."""
     pmx = _pmx()
@@ -308,6 +309,46 @@ def test_full_size_properties(layname, N):
                 assert onboard + sum(s.carry) + sum(s.ret) == lay.total_food, f"t={t} env={e}: pellets not conserved"
                 assert int(carry[e, 3].item()) == s.carry[3]
     env.close()
+
+
+def test_full_size_properties_config5_shard():
+    """BASELINE config 5's per-GPU shard: 8 192 envs, each on its OWN generated 20 x 20 maze (mazeGenerator seeds 1..8192).
+    Size-independent properties: every env shows the walls of its own maze, exactly one self cell per agent, pellets are
+    conserved against its own maze's total (food on board + carried + returned), carried counts agree between planes and
+    state, and a second handle fed the same action stream produces identical planes and rewards (no cross-env interference)."""
+    pmx = _pmx()
+    from pmx import maze_generator
+    N = 8192
+    lays = [pmx.Layout.from_text(maze_generator.generate_maze(seed)) for seed in range(1, N + 1)]
+    H, W = lays[0].height, lays[0].width
+    assert (H, W) == (20, 20)
+    envs = [pmx.PmxVecEnv(lays, N, length=60, auto_reset=True, obs_dtype="uint8", seed=5) for _ in range(2)]
+    for e in envs:
+        e.reset()
+    walls = torch.tensor(np.stack([[[(int(l.wall_rows[y]) >> x) & 1 for x in range(W)] for y in range(H)] for l in lays]),
+                         dtype=torch.uint8).cuda()
+    totals = [l.total_food for l in lays]
+    g = torch.Generator(device="cuda").manual_seed(17)
+    for t in range(150):                                    # two and a half episodes: resets happen at full size too
+        a = torch.randint(0, 5, (N, 4), generator=g, device="cuda", dtype=torch.int8)
+        o0, r0, d0, i0 = envs[0].step(a)
+        o1, r1, d1, i1 = envs[1].step(a)
+        assert torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(d0, d1), f"t={t}: the two handles diverged"
+        if t % 30 == 0 or t == 149:
+            assert torch.equal(o0[:, :, 0], walls[:, None].expand(N, 4, H, W))
+            assert torch.equal((o0[:, :, 1] > 0).sum((-1, -2)), torch.ones(N, 4, device="cuda", dtype=torch.long))
+            food_cells = (o0[:, 3, 6].long() + o0[:, 3, 7].long()).sum((-1, -2))
+            carry3 = o0[:, 3, 1].amax((-1, -2)).long() - 1
+            for first in (0, N - 96):
+                st = envs[0].get_state(first, 96)
+                for k in range(96):
+                    s, e = st[k], first + k
+                    onboard = sum(bin(s.food[y]).count("1") for y in range(H))
+                    assert onboard == int(food_cells[e].item())
+                    assert onboard + sum(s.carry) + sum(s.ret) == totals[e], f"t={t} env={e}: pellets not conserved"
+                    assert int(carry3[e].item()) == s.carry[3]
+    for e in envs:
+        e.close()
 
 
 # ------------------------------------------------------------------------------------------- other kernels

@@ -62,6 +62,64 @@ def test_model_forward_and_ppo_step_match_reference():
     _close(float(learner.bucket.data.double().abs().sum()), d["post_adam_abs"], rtol=1e-6)
 
 
+def sharpen_init(model):
+    """Same transform as tests/golden/make_golden.py::sharpen_init (logits and values of O(1) from the seeded initialisation)."""
+    with torch.no_grad():
+        model.actor_head[3].weight.mul_(120.0)
+        model.critic_head[2].weight.mul_(6.0)
+        model.critic_projector[0].weight.mul_(2.5)
+        for j, (name, p) in enumerate(model.named_parameters()):
+            if p.dim() == 1 and name.endswith("bias"):
+                p.add_(0.1 * torch.sin(0.37 * torch.arange(p.numel(), dtype=torch.float64) + 1.3 * j).to(p.dtype))
+
+
+def reference_init_model(tag, shape, seed):
+    """MAPPOAgent as the REFERENCE initialises it under torch.manual_seed(seed) (fixture G7b stores the seed and per-tensor
+    checksums instead of the weights): the module list, the creation order and the init calls mirror
+    pacman_mappo_resnet.py:97-158, so the same seed draws the same weights."""
+    from pmx import mappo
+    n_thr = torch.get_num_threads()
+    torch.set_num_threads(1)               # as the generator: the QR behind nn.init.orthogonal_ rounds differently with more threads
+    try:
+        torch.manual_seed(seed)
+        model = mappo.MAPPOAgent(shape, 5, 2)
+    finally:
+        torch.set_num_threads(n_thr)
+    if tag == "sharp":
+        sharpen_init(model)
+    return model
+
+
+def _init_batch(tag):
+    d, meta = G.load("ppo_init.npz")
+    t = lambda k, dt=torch.float32: torch.tensor(d[k]).to(dt)
+    return (d, meta, t("obs"), t("merged"), t(f"{tag}_act", torch.long), t(f"{tag}_old_logp"), t(f"{tag}_adv"), t(f"{tag}_ret"))
+
+
+@pytest.mark.parametrize("tag", ["init", "sharp"])
+def test_reference_initialisation_fixture_fp32(tag):
+    """G7b: the reference's own seeded initialisation is reproduced weight for weight (per-tensor sums), and the float32 model
+    gives the reference's logits, values, log-probabilities, entropies, losses and per-tensor gradient norms within 1e-4 on
+    the paired batch (merged input k serves rows 2k and 2k + 1)."""
+    from pmx import mappo
+    torch.set_num_threads(2)
+    d, meta, obs, merged, act, old_logp, adv, ret = _init_batch(tag)
+    model = reference_init_model(tag, tuple(obs.shape[1:]), meta["seed"])
+    assert [n for n, _ in model.named_parameters()] == meta["param_names"]
+    # (the same draws; a LAPACK build or thread count that rounds the QR differently moves a sum in its 6th digit at most)
+    _close([float(p.detach().double().sum()) for p in model.parameters()], d[f"{tag}_param_sum"], rtol=2e-5, atol=2e-5)
+    _close([float(p.detach().double().abs().sum()) for p in model.parameters()], d[f"{tag}_param_abs"], rtol=2e-5, atol=2e-5)
+    with torch.no_grad():
+        _close(model.logits(obs).numpy(), d[f"{tag}_logits"])
+        _close(model.value(merged).repeat_interleave(2).numpy(), d[f"{tag}_values"])
+    loss, stats = mappo.ppo_loss(model, obs, merged, act, old_logp, adv, ret, meta["clip_eps"], meta["ent_coef"])
+    _close(stats["pg"], d[f"{tag}_pg"]); _close(stats["vl"], d[f"{tag}_vl"]); _close(loss.item(), d[f"{tag}_loss"])
+    _close(stats["entropy"], np.mean(d[f"{tag}_entropy"]))
+    grads = torch.autograd.grad(loss, list(model.parameters()))
+    _close([float(g.double().norm()) for g in grads], d[f"{tag}_grad_norms"], rtol=2e-4, atol=1e-7)
+    _close(float(torch.linalg.vector_norm(torch.stack([g.norm() for g in grads]))), d[f"{tag}_grad_norm"])
+
+
 def test_flat_bucket_adam_equals_torch_adam():
     from pmx import mappo
     torch.manual_seed(0)

@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, nargs="+", default=[512, 8192, 32768])
 ap.add_argument("--layout", default="smallCapture")
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--no-library", action="store_true", help="time the fused kernels only")
 args = ap.parse_args()
 lay = pmx.get_layout(args.layout)
 H, W = lay.height, lay.width
@@ -55,8 +56,9 @@ for B in args.batch:
         with torch.autocast("cuda", dtype=torch.bfloat16):
             out = m.actor_backbone(obs.contiguous(memory_format=torch.channels_last))
         torch.autograd.grad(out.float().sum(), params)
-    res["library_infer_ms"] = timeit(lib_infer, args.iters) * 1e3
-    res["library_fwd_bwd_ms"] = timeit(lib_train, args.iters) * 1e3
+    if not args.no_library:
+        res["library_infer_ms"] = timeit(lib_infer, args.iters) * 1e3
+        res["library_fwd_bwd_ms"] = timeit(lib_train, args.iters) * 1e3
     res["fused_infer_TFLOPs"] = B * FLOP / (res["fused_infer_ms"] * 1e-3) / 1e12
     res["fused_fwd_bwd_TFLOPs"] = 3 * B * FLOP / (res["fused_fwd_bwd_ms"] * 1e-3) / 1e12
     print(json.dumps(res), flush=True)
