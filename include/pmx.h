@@ -376,6 +376,28 @@ int pmx_tok32ln_forward(const void *x_dev, const void *a_dev, const void *pack_d
 int pmx_tok32ln_backward(const void *x_dev, const void *a_dev, const void *dy_dev, const void *pack_dev, void *dx_dev, void *da_dev,
                          float *grad_dev, int64_t tokens, float eps, void *stream);
 
+/* ---- The small ends of the two heads, one kernel each way (csrc/pmx_heads.hip) ----------------------------------------
+ * Actor tail (pacman_mappo_resnet.py:117-122, actor_head[1:]): logits = W2 gelu(LayerNorm_512(h)) + b2 on the 512-wide output h
+ * [B][512] (bfloat16 if h_bf16, else float32) of the first head layer; logits_dev [B][5] float32; stats_dev [B][2] float32 (mean,
+ * rstd; may be NULL for inference).  Backward: dh_dev [B][512] in h's type, and the parameter gradients in row 0 of grad_dev
+ * [1 + PMX_HEADS_PARTIAL_ROWS][PMX_ACTOR_TAIL_GRAD_FLOATS]: dW2 [5][512], db2 [5] (+ 3 unused), dLN.weight [512], dLN.bias [512].
+ * Critic tail (:143-147 critic_head on the mean over tokens, :169): value = w2 gelu(W1 mean_s tokens[b][s] + b1) + b2 with tokens
+ * [B][S][32] bfloat16 (the batch-major encoder output); pooled_dev [B][32] float32 is saved for backward.  Backward: dtokens_dev
+ * [B][S][32] bfloat16, scratch_dev 2 * B * 512 bfloat16, row 0 of grad_dev [1 + PMX_HEADS_PARTIAL_ROWS][PMX_CRITIC_TAIL_GRAD_FLOATS]: dW1
+ * [512][32], db1 [512], dw2 [512], db2 [1] (+ 7 unused).  Parameters are float32 device pointers with nn.Module shapes; the kernels round the two linears' weights
+ * and inputs to bfloat16 as autocast does and keep LayerNorm / GELU in float32. */
+#define PMX_HEADS_PARTIAL_ROWS 128
+#define PMX_ACTOR_TAIL_GRAD_FLOATS 3592
+#define PMX_CRITIC_TAIL_GRAD_FLOATS 17416
+int pmx_actor_tail_forward(const void *h_dev, int32_t h_bf16, const float *ln_w, const float *ln_b, const float *w2, const float *b2,
+                           float *logits_dev, float *stats_dev, int64_t B, float eps, void *stream);
+int pmx_actor_tail_backward(const void *h_dev, int32_t h_bf16, const float *stats_dev, const float *dlogits_dev, const float *ln_w,
+                            const float *ln_b, const float *w2, void *dh_dev, float *grad_dev, int64_t B, void *stream);
+int pmx_critic_tail_forward(const void *tokens_dev, const float *w1, const float *b1, const float *w2, const float *b2,
+                            float *value_dev, float *pooled_dev, int64_t B, int32_t S, void *stream);
+int pmx_critic_tail_backward(const float *pooled_dev, const float *dvalue_dev, const float *w1, const float *b1, const float *w2,
+                             void *dtokens_dev, void *scratch_dev, float *grad_dev, int64_t B, int32_t S, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,7 @@ FFN_PACK_BYTES = 33664
 FFN_GRAD_FLOATS = 8416
 TOK96_PACK_BYTES, TOK96_GRAD_FLOATS = 12928, 3232
 TOK32_PACK_BYTES, TOK32_GRAD_FLOATS = 4480, 1120
+HEADS_PARTIAL_ROWS, ACTOR_TAIL_GRAD_FLOATS, CRITIC_TAIL_GRAD_FLOATS = 128, 3592, 17416
 
 
 class PmxError(RuntimeError):
@@ -109,6 +110,10 @@ PROTOTYPES = [
     ("pmx_tok32ln_pack", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     ("pmx_tok32ln_forward", C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_float, _VP]),
     ("pmx_tok32ln_backward", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_float, _VP]),
+    ("pmx_actor_tail_forward", C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_float, _VP]),
+    ("pmx_actor_tail_backward", C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
+    ("pmx_critic_tail_forward", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _I32, _VP]),
+    ("pmx_critic_tail_backward", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _I32, _VP]),
 ]
 # test / bench hooks that are not part of the public header
 EXTRA = [

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpmx_hip.so")
 OBJDIR = os.path.join(HERE, "build")
-SOURCES = ["pmx_step.hip", "pmx_api.hip", "pmx_train.hip", "pmx_actor.hip", "pmx_critic.hip"]
+SOURCES = ["pmx_step.hip", "pmx_api.hip", "pmx_train.hip", "pmx_actor.hip", "pmx_critic.hip", "pmx_heads.hip"]
 HEADERS = ["pmx_device.h", os.path.join("..", "..", "include", "pmx.h")]
 # -ffp-contract=off: the float64 reward sums and the float32 GAE scan must round like the reference's Python/torch ops
 # (the network kernels opt back in per file with `#pragma clang fp contract(fast)`)

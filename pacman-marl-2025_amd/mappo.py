@@ -264,6 +264,79 @@ def attention8(qkv, batch_major=False):
     return _Attention8.apply(qkv, batch_major)
 
 
+class _ActorTail(torch.autograd.Function):
+    """logits = Linear_5(gelu(LayerNorm_512(h))) through pmx_actor_tail_forward / _backward (csrc/pmx_heads.hip): one launch each
+    way (+ a row sum) instead of LayerNorm, GELU, a skinny GEMM, their backward kernels, two bias reductions and the casts."""
+
+    @staticmethod
+    def forward(ctx, h, lnw, lnb, w2, b2, eps):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        h = h.contiguous()
+        B = h.shape[0]
+        logits = torch.empty(B, 5, dtype=torch.float32, device=h.device)
+        stats = torch.empty(B, 2, dtype=torch.float32, device=h.device)
+        st = C.c_void_p(torch.cuda.current_stream(h.device).cuda_stream)
+        _lib.check(lib.pmx_actor_tail_forward(h.data_ptr(), 1 if h.dtype == torch.bfloat16 else 0, lnw.data_ptr(), lnb.data_ptr(), w2.data_ptr(),
+                                              b2.data_ptr(), logits.data_ptr(), stats.data_ptr(), B, float(eps), st), "pmx_actor_tail_forward")
+        ctx.save_for_backward(h, stats, lnw, lnb, w2)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        h, stats, lnw, lnb, w2 = ctx.saved_tensors
+        B = h.shape[0]
+        dlogits = dlogits.float().contiguous()
+        dh = torch.empty_like(h)
+        G = _lib.ACTOR_TAIL_GRAD_FLOATS
+        grad = torch.empty((1 + _lib.HEADS_PARTIAL_ROWS) * G, dtype=torch.float32, device=h.device)
+        st = C.c_void_p(torch.cuda.current_stream(h.device).cuda_stream)
+        _lib.check(lib.pmx_actor_tail_backward(h.data_ptr(), 1 if h.dtype == torch.bfloat16 else 0, stats.data_ptr(), dlogits.data_ptr(),
+                                               lnw.data_ptr(), lnb.data_ptr(), w2.data_ptr(), dh.data_ptr(), grad.data_ptr(), B, st), "pmx_actor_tail_backward")
+        return dh, grad[2568:3080], grad[3080:3592], grad[:2560].view(5, 512), grad[2560:2565], None
+
+
+class _CriticTail(torch.autograd.Function):
+    """value = Linear_1(gelu(Linear_512(mean over tokens))) through pmx_critic_tail_forward / _backward: the mean pool, both
+    linears, the GELU and -- backwards -- the broadcast of the pooled gradient over the tokens and all four parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, tokens, w1, b1, w2, b2):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        tokens = tokens.contiguous()
+        B, S, _ = tokens.shape
+        value = torch.empty(B, dtype=torch.float32, device=tokens.device)
+        pooled = torch.empty(B, 32, dtype=torch.float32, device=tokens.device)
+        st = C.c_void_p(torch.cuda.current_stream(tokens.device).cuda_stream)
+        _lib.check(lib.pmx_critic_tail_forward(tokens.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), value.data_ptr(),
+                                               pooled.data_ptr(), B, S, st), "pmx_critic_tail_forward")
+        ctx.save_for_backward(pooled, w1, b1, w2)
+        ctx.S = S
+        return value
+
+    @staticmethod
+    def backward(ctx, dvalue):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        pooled, w1, b1, w2 = ctx.saved_tensors
+        B, S, dev = pooled.shape[0], ctx.S, pooled.device
+        dvalue = dvalue.float().contiguous()
+        dtok = torch.empty(B, S, 32, dtype=torch.bfloat16, device=dev)
+        scratch = torch.empty(2 * B * 512, dtype=torch.bfloat16, device=dev)
+        grad = torch.empty((1 + _lib.HEADS_PARTIAL_ROWS) * _lib.CRITIC_TAIL_GRAD_FLOATS, dtype=torch.float32, device=dev)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.pmx_critic_tail_backward(pooled.data_ptr(), dvalue.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), dtok.data_ptr(),
+                                                scratch.data_ptr(), grad.data_ptr(), B, S, st), "pmx_critic_tail_backward")
+        return dtok, grad[:16384].view(512, 32), grad[16384:16896], grad[16896:17408].view(1, 512), grad[17408:17409]
+
+
 def column_sums(t):
     """t.sum over all but the last dimension, in float32: the HIP column-sum kernel for a contiguous bfloat16 tensor on the
     GPU whose last dimension is a multiple of 8 (<= 256), torch's reduction otherwise."""
@@ -504,6 +577,17 @@ class MAPPOAgent(nn.Module):
     tower_pack = None       # packed tower parameters for inference, set by a caller that knows the weights are frozen
                             # (VecMAPPOTrainer.rollout); None = pack on every call
 
+    fused_heads = True      # the small ends of the two heads as one kernel each way under bf16 autocast (csrc/pmx_heads.hip)
+
+    def _fused_heads_ok(self, t):
+        """The head-tail kernels take bfloat16 activations under bf16 autocast on the GPU and float32 master weights of the
+        reference's shapes (they round the linears' operands to bf16 themselves, as autocast does)."""
+        ah, ch = self.actor_head, self.critic_head
+        return (self.fused_heads and t.is_cuda and t.dtype == torch.bfloat16 and torch.is_autocast_enabled()
+                and ah[3].weight.dtype == torch.float32 and ch[0].weight.dtype == torch.float32 and ch[2].weight.dtype == torch.float32
+                and tuple(ah[3].weight.shape) == (5, 512) and tuple(ch[0].weight.shape) == (512, 32) and tuple(ch[2].weight.shape) == (1, 512)
+                and ah[1].weight.dtype == torch.float32)
+
     def _use_fused_tower(self, obs):
         if not (self.fused_tower and obs.is_cuda and obs.dim() == 4 and obs.dtype in (torch.bfloat16, torch.uint8)):
             return False
@@ -528,6 +612,9 @@ class MAPPOAgent(nn.Module):
             HW = feat.shape[1]
             w = lin.weight.view(lin.out_features, 32, HW).permute(0, 2, 1).reshape(lin.out_features, HW * 32)
             h = F.linear(feat.reshape(feat.shape[0], HW * 32), w, lin.bias)
+            if self._fused_heads_ok(h) and h.shape[1] == 512:
+                ln, out = self.actor_head[1], self.actor_head[3]
+                return _ActorTail.apply(h, ln.weight, ln.bias, out.weight, out.bias, ln.eps)
             return self.actor_head[1:](h)
         if obs.dtype == torch.uint8:            # byte planes are an input format of the fused tower only
             obs = obs.to(torch.bfloat16 if (obs.is_cuda and torch.is_autocast_enabled()) else torch.float32)
@@ -557,6 +644,9 @@ class MAPPOAgent(nn.Module):
                 x = layer.forward_batch_major(x)
             if self.critic_transformer.norm is not None:
                 x = self.critic_transformer.norm(x)
+            if self._fused_heads_ok(x):
+                l1, l2 = self.critic_head[0], self.critic_head[2]
+                return _CriticTail.apply(x, l1.weight, l1.bias, l2.weight, l2.bias)
             return self.critic_head(x.mean(dim=1)).squeeze(-1)
         x = self.pos_encoder(self.critic_projector(merged_obs))
         x = x.flatten(2).permute(2, 0, 1)                                # [H*W, B, d]
@@ -836,6 +926,7 @@ class PPOLearner:
     # the WHOLE bucket instead (one cast kernel after the optimizer step); the copy's slices take the parameters' places for the
     # forward pass and receive the gradients, which pmx_flatten_to_f32 widens into the bucket.  Same roundings as autocast's.
     SHADOWED = ("actor_head.0.", "actor_head.3.", "critic_projector.0.", "critic_head.0.", "critic_head.2.")
+    SHADOWED_WITH_FUSED_HEADS = ("actor_head.0.", "critic_projector.0.")    # (the head-tail kernels read the small layers' float32 masters)
     shadow_weights = True
 
     def _shadow_context(self):
@@ -850,7 +941,7 @@ class PPOLearner:
             names = [n for n, p in self.model.named_parameters() if p.requires_grad]
             self._shadow_slots, off = [], 0
             for i, (n, p) in enumerate(zip(names, self.bucket.params)):
-                if n.startswith(self.SHADOWED):
+                if n.startswith(self.SHADOWED_WITH_FUSED_HEADS if getattr(self.model, "fused_heads", False) else self.SHADOWED):
                     self._shadow_slots.append((i, n, off, p.numel(), tuple(p.shape)))
                 off += p.numel()
         self._shadow_views, pd = {}, {}

@@ -595,6 +595,8 @@ def test_batch_major_critic_matches_sequence_major_critic():
     m = mappo.MAPPOAgent((8, H, W)).cuda()
     merged = (torch.rand(96, 8, H, W, device="cuda") < 0.2).to(torch.uint8)
     res = {}
+    m.fused_heads = False          # (the head-tail kernels only exist on the batch-major path and have their own tests: here both
+                                   #  layouts run the library head, so that the comparison is about the token layout alone)
     for bm in (False, True):
         m.batch_major_critic = bm
         m.zero_grad(set_to_none=True)
@@ -771,3 +773,81 @@ def test_bf16_shadow_weights_give_the_autocast_step():
     p_rel = float((res[True][1] - res[False][1]).norm() / res[False][1].norm())
     assert g_rel <= 2e-2 and p_rel <= 1e-4, (g_rel, p_rel)
     assert abs(res[True][2] - res[False][2]) <= 2e-2 * (abs(res[False][2]) + 1e-2)
+
+
+@pytest.mark.parametrize("B", [512, 37, 3])
+def test_fused_actor_tail_matches_torch(B):
+    """pmx_actor_tail_forward / _backward (LayerNorm_512 -> GELU -> Linear_5 of actor_head, pacman_mappo_resnet.py:117-122)
+    against torch in float64 on the operands the kernel uses (hidden activations and W2 rounded to bf16): logits within 2e-3
+    absolute (bf16 activations of O(1) summed over 512 terms), input and parameter gradients within 2e-2 of their largest entry."""
+    from pmx import mappo
+    torch.manual_seed(B)
+    h = (torch.randn(B, 512, device="cuda") * 1.5 + 0.2).to(torch.bfloat16).requires_grad_(True)
+    ln = torch.nn.LayerNorm(512).cuda()
+    out = torch.nn.Linear(512, 5).cuda()
+    with torch.no_grad():
+        ln.weight.copy_(1.0 + 0.2 * torch.randn(512, device="cuda")); ln.bias.copy_(0.1 * torch.randn(512, device="cuda"))
+        out.weight.mul_(3.0)
+    dl = torch.randn(B, 5, device="cuda")
+    logits = mappo._ActorTail.apply(h, ln.weight, ln.bias, out.weight, out.bias, ln.eps)
+    got = torch.autograd.grad((logits * dl).sum(), [h, ln.weight, ln.bias, out.weight, out.bias])
+    bf = lambda t: t.to(torch.bfloat16).double()
+    h2 = h.detach().double().requires_grad_(True)
+    lw, lb = ln.weight.detach().double().requires_grad_(True), ln.bias.detach().double().requires_grad_(True)
+    w2 = out.weight.detach().double().requires_grad_(True)
+    b2 = out.bias.detach().double().requires_grad_(True)
+    g = torch.nn.functional.gelu(torch.nn.functional.layer_norm(h2, (512,), lw, lb, ln.eps))
+    g = g + (bf(g.detach()) - g.detach())                                       # straight-through bf16 rounding of the GELU output
+    w2r = w2 + (bf(w2.detach()) - w2.detach())
+    ref = g @ w2r.t() + b2
+    want = torch.autograd.grad((ref * dl.double()).sum(), [h2, lw, lb, w2, b2])
+    assert float((logits.double() - ref).abs().max()) <= 2e-3 * (1.0 + float(ref.abs().max()))
+    for name, a, b in zip(("dh", "dlnw", "dlnb", "dw2", "db2"), got, want):
+        assert a.shape == b.shape
+        assert float((a.double() - b).abs().max()) <= 2e-2 * (float(b.abs().max()) + 1e-6), name
+
+
+@pytest.mark.parametrize("B,S", [(256, 154), (19, 400), (2, 7), (1500, 33)])
+def test_fused_critic_tail_matches_torch(B, S):
+    """pmx_critic_tail_forward / _backward (mean over tokens -> Linear_512 -> GELU -> Linear_1, pacman_mappo_resnet.py:143-147, :169)
+    against torch in float64 with the kernel's bf16 roundings made explicit."""
+    from pmx import mappo
+    torch.manual_seed(B + S)
+    tok = (torch.randn(B, S, 32, device="cuda") * 1.2 + 0.3 * torch.randn(B, 1, 32, device="cuda")).to(torch.bfloat16).requires_grad_(True)
+    l1, l2 = torch.nn.Linear(32, 512).cuda(), torch.nn.Linear(512, 1).cuda()
+    with torch.no_grad():
+        l1.weight.mul_(2.0); l1.bias.add_(0.1 * torch.randn(512, device="cuda")); l2.weight.mul_(4.0)
+    dv = torch.randn(B, device="cuda")
+    val = mappo._CriticTail.apply(tok, l1.weight, l1.bias, l2.weight, l2.bias)
+    got = torch.autograd.grad((val * dv).sum(), [tok, l1.weight, l1.bias, l2.weight, l2.bias])
+    ste = lambda t: t + (t.detach().to(torch.bfloat16).double() - t.detach())
+    t2 = tok.detach().double().requires_grad_(True)
+    ps = [p.detach().double().requires_grad_(True) for p in (l1.weight, l1.bias, l2.weight, l2.bias)]
+    pooled = ste(t2.mean(1))
+    pre = ste(pooled @ ste(ps[0]).t() + ste(ps[1]))
+    ref = (ste(torch.nn.functional.gelu(pre)) @ ste(ps[2]).t()).squeeze(-1) + ps[3]
+    want = torch.autograd.grad((ref * dv.double()).sum(), [t2] + ps)
+    assert float((val.double() - ref).abs().max()) <= 3e-3 * (1.0 + float(ref.abs().max()))
+    for name, a, b in zip(("dtokens", "dw1", "db1", "dw2", "db2"), got, want):
+        assert a.shape == b.shape, name
+        assert float((a.double() - b).abs().max()) <= 3e-2 * (float(b.abs().max()) + 1e-6), name
+
+
+def test_fused_heads_are_what_the_model_uses_under_autocast():
+    """MAPPOAgent.logits / value take the head-tail kernels under bf16 autocast (byte planes, batch-major critic) and agree with the
+    library path (fused_heads off) to bf16 accuracy."""
+    from pmx import mappo
+    torch.manual_seed(4)
+    m = mappo.MAPPOAgent((8, 11, 14), 5, 2).cuda()
+    with torch.no_grad():
+        m.actor_head[3].weight.mul_(60.0); m.critic_head[2].weight.mul_(5.0)
+    obs = (torch.rand(96, 8, 11, 14, device="cuda") < 0.2).to(torch.uint8)
+    res = {}
+    for on in (True, False):
+        m.fused_heads = on
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            res[on] = (m.logits(obs).float(), m.value(obs).float())
+    m.fused_heads = True
+    assert res[True][0].dtype == torch.float32
+    assert float((res[True][0] - res[False][0]).abs().max()) <= 3e-2 * (1.0 + float(res[False][0].abs().max()))
+    assert float((res[True][1] - res[False][1]).abs().max()) <= 3e-2 * (1.0 + float(res[False][1].abs().max()))
