@@ -421,6 +421,11 @@ def main():
     emit = None
     if not args.no_emit:
         emit = emit_team_probe(lay, n_envs, length, dev, rank, actions)
+        try:
+            if n_envs == WORKLOADS[args.workload][1]:
+                emit["traffic"] = json.load(open(tpath)).get(f"{args.workload}:emit_uint8", {}).get("expand_hbm_bytes_per_launch")
+        except Exception:
+            pass
 
     if rank == 0:
         B = algorithmic_bytes(H, W, e)

@@ -231,6 +231,15 @@ __global__ __launch_bounds__(256, 2) void pmx_actor_fwd_kernel(const IN_T *__res
     G.H = H, G.W = W, G.WP = W + 2, G.HW = H * W, G.MP = map_positions(NT, W + 2);
     char *map = smem + (size_t)wave * G.MP * 64;
     for (int i = lane; i < G.MP * 4; i += 64) reinterpret_cast<uint4 *>(map)[i] = uint4{0, 0, 0, 0};
+    // position (tile t, column p) -> board cell (or -1): the index of the feature row the last layer writes.  A table, because the
+    // row / column split is a division by the run-time padded width, which the compiler evaluated for every tile of EVERY layer
+    // (~15 vector instructions each, a tenth of the kernel's vector work) although only the last layer stores features.
+    __shared__ int cell_tab[NT * 16];
+    for (int i = threadIdx.x; i < NT * 16; i += 256) {
+        const int q = G.WP + i, row = q / G.WP, col = q - row * G.WP;
+        cell_tab[i] = (col >= 1 && col <= W && row <= H) ? (row - 1) * W + (col - 1) : -1;
+    }
+    __syncthreads();
     // which of the lane's NT positions are board cells
     uint32_t vmask = 0;
 #pragma unroll
@@ -380,9 +389,9 @@ __global__ __launch_bounds__(256, 2) void pmx_actor_fwd_kernel(const IN_T *__res
                     const uint2 y2 = {pack2(v[0], v[1]), pack2(v[2], v[3])};
                     *reinterpret_cast<uint2 *>(wbase + (WPv + 16 * t) * 64 + m * 32) = y2;
                     if (write_y) ydst[(t * 2 + m) * 64] = y2;
-                    if (l == NLAYER - 1 && vm != 0.0f) {
-                        const int q = WPv + 16 * t + p, row = q / WPv, col = q - row * WPv;
-                        feat[((size_t)s * G.HW + (row - 1) * W + (col - 1)) * 8 + 4 * m + g] = y2;
+                    if (l == NLAYER - 1) {
+                        const int ci = cell_tab[16 * t + p];
+                        if (ci >= 0) feat[((size_t)s * G.HW + ci) * 8 + 4 * m + g] = y2;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -440,6 +449,11 @@ __global__ __launch_bounds__(256, 2) void pmx_actor_fwd_split_kernel(const IN_T 
     char *map = smem + (size_t)sub * G.MP * 64;
     float *xs = reinterpret_cast<float *>(smem + (size_t)SPB * G.MP * 64) + sub * (WS * 8);   // [WS waves][4 groups][sum, sum of squares]
     for (int i = threadIdx.x; i < SPB * G.MP * 4; i += 256) reinterpret_cast<uint4 *>(smem)[i] = uint4{0, 0, 0, 0};
+    __shared__ int cell_tab[NT * 16];                           // position -> board cell of the feature row (see pmx_actor_fwd_kernel)
+    for (int i = threadIdx.x; i < NT * 16; i += 256) {
+        const int q = G.WP + i, row = q / G.WP, col = q - row * G.WP;
+        cell_tab[i] = (col >= 1 && col <= W && row <= H) ? (row - 1) * W + (col - 1) : -1;
+    }
     const int t0 = __builtin_amdgcn_readfirstlane(wq * NTW);
     const int tid_s = threadIdx.x - sub * (WS * 64);           // thread index within the sample's waves
     uint32_t vmask = 0;                                         // which of the lane's positions in the wave's tiles are board cells
@@ -574,9 +588,9 @@ __global__ __launch_bounds__(256, 2) void pmx_actor_fwd_split_kernel(const IN_T 
                         const uint2 y2 = {pack2(v[0], v[1]), pack2(v[2], v[3])};
                         *reinterpret_cast<uint2 *>(wbase + (WPv + 16 * t) * 64 + m * 32) = y2;
                         if (write_y) ydst[(t * 2 + m) * 64] = y2;
-                        if (l == NLAYER - 1 && vm != 0.0f) {
-                            const int q = WPv + 16 * t + p, row = q / WPv, col = q - row * WPv;
-                            feat[((size_t)s * G.HW + (row - 1) * W + (col - 1)) * 8 + 4 * m + g] = y2;
+                        if (l == NLAYER - 1) {
+                            const int ci = cell_tab[16 * t + p];
+                            if (ci >= 0) feat[((size_t)s * G.HW + ci) * 8 + 4 * m + g] = y2;
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }

@@ -1250,61 +1250,100 @@ __global__ __launch_bounds__(256 * QS) void pmx_attn8_bwd_fused_kernel(const __h
     // fills in groups 1..3 meet the zeros of the B operand (the V rows live in group 0 only), so they need no masking
     const short *dOr_lane = dOr + (size_t)c * D;
     const int tr_row = (lane & 15) >> 2, tr_pc = lane & 3;
+    // The K / V rows of a key tile come from global memory and its dK / dV rows go back there; loads and stores share one in-order
+    // counter, so rows requested at the top of a tile would wait behind the previous tile's stores (a full write round trip per
+    // tile).  They are requested one tile AHEAD, in front of those stores.
+    pmx_bf16x8 kf_n = row8(base, row_stride, head_off + E, c), vf_n = row8(base, row_stride, head_off + 2 * E, c);
     for (int kt = 0; kt < n_t; ++kt) {
         const int k_row = kt * 16 + c;
-        const pmx_bf16x8 kf = row8(base, row_stride, head_off + E, k_row);
-        const pmx_bf16x8 vf = row8(base, row_stride, head_off + 2 * E, k_row);
+        const pmx_bf16x8 kf = kf_n, vf = vf_n;
+        if (kt + 1 < n_t) {
+            kf_n = row8(base, row_stride, head_off + E, k_row + 16);
+            vf_n = row8(base, row_stride, head_off + 2 * E, k_row + 16);
+        }
         // A operand of dQ^T += K^T . dS^T for this key tile: row d = c, k-slot (g, j) = key 16 kt + 8 g + j (groups 2, 3: none)
         pmx_bf16x8 ka = zero8;
         if (c < D && g < 2) ka = *reinterpret_cast<const pmx_bf16x8 *>(Kt + (size_t)c * S_pad + kt * 16 + 8 * g);
         pmx_f32x4 dk = z4, dv = z4;
+        // The pairs of a key tile as a SOFTWARE PIPELINE.  One pair is a chain  operand reads -> score products -> exponentials ->
+        // dV / dK products, dS to the staging rows -> transposing reads -> dQ products, and with two waves per SIMD nothing else
+        // covers its three LDS round trips (the kernel sat at ~50 % vector-ALU issue).  So the steps of consecutive pairs are
+        // interleaved by hand, every consumer at least one other step behind its producer, and scheduling barriers keep the
+        // compiler from re-serialising them:
+        //   [reads j+1 | fragment reads j] [exponentials j] [dV, dK products j; dS j -> staging; transposing reads j]
+        //   [score products j+1] [dQ products j]
+        struct Ops { pmx_f32x4 nl0, nl1, nd0, nd1; pmx_bf16x8 d0, d1; };
+        struct Sc { pmx_f32x4 s0, s1, p0, p1; };
+        auto pair_live = [&](int j) { return !(QS > 1 && NQP * QS > NPF && j == NQP - 1 && qp0 + j >= NPF); };   // wave-uniform: the last
+                                                                          // wave owns one pair less (run-time only for j = NQP - 1)
+        auto read_ops = [&](int j) -> Ops {
+            const int qp = qp0 + j;
+            Ops o;
+            // (accumulator row r of lane group g is query 32 qp + 4 g + r, resp. + 16: four consecutive floats each)
+            o.nl0 = *reinterpret_cast<const pmx_f32x4 *>(lse_s + qp * 32 + g * 4), o.nl1 = *reinterpret_cast<const pmx_f32x4 *>(lse_s + qp * 32 + 16 + g * 4);
+            o.nd0 = *reinterpret_cast<const pmx_f32x4 *>(delta_s + qp * 32 + g * 4), o.nd1 = *reinterpret_cast<const pmx_f32x4 *>(delta_s + qp * 32 + 16 + g * 4);
+            if (QS > 1) {
+                o.d0 = *reinterpret_cast<const pmx_bf16x8 *>(dOr_lane + (size_t)(qp * 32) * D);
+                o.d1 = *reinterpret_cast<const pmx_bf16x8 *>(dOr_lane + (size_t)(qp * 32 + 16) * D);
+            } else {
+                o.d0 = dr[QS > 1 ? 0 : 2 * j], o.d1 = dr[QS > 1 ? 0 : 2 * j + 1];
+            }
+            return o;
+        };
+        auto score = [&](int j, const Ops &o) -> Sc {
+            Sc r;
+            r.s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[2 * j], kf, o.nl0, 0, 0, 0);
+            r.s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[2 * j + 1], kf, o.nl1, 0, 0, 0);
+            r.p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o.d0, vf, o.nd0, 0, 0, 0);
+            r.p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o.d1, vf, o.nd1, 0, 0, 0);
+            return r;
+        };
+        Sc cur = score(0, read_ops(0));
 #pragma unroll
         for (int j = 0; j < NQP; ++j) {
             const int qp = qp0 + j;
-            if (QS > 1 && NQP * QS > NPF && j == NQP - 1 && qp >= NPF) continue;   // wave-uniform: the last wave owns one pair less (only ITS last
-                                                                                    // step is conditional, so the others form one scheduling region)
-            // (accumulator row r of lane group g is query 32 qp + 4 g + r, resp. + 16: four consecutive floats each)
-            const pmx_f32x4 nl0 = *reinterpret_cast<const pmx_f32x4 *>(lse_s + qp * 32 + g * 4), nl1 = *reinterpret_cast<const pmx_f32x4 *>(lse_s + qp * 32 + 16 + g * 4);
-            const pmx_f32x4 nd0 = *reinterpret_cast<const pmx_f32x4 *>(delta_s + qp * 32 + g * 4), nd1 = *reinterpret_cast<const pmx_f32x4 *>(delta_s + qp * 32 + 16 + g * 4);
-            const pmx_f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[2 * j], kf, nl0, 0, 0, 0);
-            const pmx_f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[2 * j + 1], kf, nl1, 0, 0, 0);
-            pmx_bf16x8 d0, d1;
-            if (QS > 1) {
-                d0 = *reinterpret_cast<const pmx_bf16x8 *>(dOr_lane + (size_t)(qp * 32) * D);
-                d1 = *reinterpret_cast<const pmx_bf16x8 *>(dOr_lane + (size_t)(qp * 32 + 16) * D);
-            } else {
-                d0 = dr[2 * j], d1 = dr[2 * j + 1];
-            }
-            const pmx_f32x4 p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0, vf, nd0, 0, 0, 0);
-            const pmx_f32x4 p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1, vf, nd1, 0, 0, 0);
+            if (!pair_live(j)) continue;
+            const bool more = j + 1 < NQP && pair_live(j + 1);
+            // ---- reads for the next pair's score products and this pair's transposed fragments, then this pair's exponentials
+            Ops nxt_ops;
+            if (more) nxt_ops = read_ops(j + 1);
+            const pmx_bf16x8 fo = tfrag(dOt, qp), fq = tfrag(Qt, qp);
             float e0[4], e1[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                e0[r] = __builtin_amdgcn_exp2f(s0[r] * c2);
-                e1[r] = __builtin_amdgcn_exp2f(s1[r] * c2);
+                e0[r] = __builtin_amdgcn_exp2f(cur.s0[r] * c2);
+                e1[r] = __builtin_amdgcn_exp2f(cur.s1[r] * c2);
             }
             // probabilities and dS as bf16 pairs: slots 0..3 = queries 4g + r of the first tile of the pair, 4..7 = of the second
             const uint4 pw = make_uint4(pack2bf(e0[0], e0[1]), pack2bf(e0[2], e0[3]), pack2bf(e1[0], e1[1]), pack2bf(e1[2], e1[3]));
-            const uint4 dw = make_uint4(pack2bf(e0[0] * p0[0], e0[1] * p0[1]), pack2bf(e0[2] * p0[2], e0[3] * p0[3]),
-                                        pack2bf(e1[0] * p1[0], e1[1] * p1[1]), pack2bf(e1[2] * p1[2], e1[3] * p1[3]));
+            const uint4 dw = make_uint4(pack2bf(e0[0] * cur.p0[0], e0[1] * cur.p0[1]), pack2bf(e0[2] * cur.p0[2], e0[3] * cur.p0[3]),
+                                        pack2bf(e1[0] * cur.p1[0], e1[1] * cur.p1[1]), pack2bf(e1[2] * cur.p1[2], e1[3] * cur.p1[3]));
             const pmx_bf16x8 pf = *reinterpret_cast<const pmx_bf16x8 *>(&pw), dsf = *reinterpret_cast<const pmx_bf16x8 *>(&dw);
-            dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(dOt, qp), pf, dv, 0, 0, 0);
-            dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Qt, qp), dsf, dk, 0, 0, 0);
-            // dS of the tile as [key c][queries 4g .. 4g+3 | 16 + 4g ..] -> staging rows 0..15 (a padded key's column holds whatever
-            // the zero K row produced; its K^T entries in `ka` are zero, so it adds nothing).  The write, the transposing reads below
-            // and the next pair's write are LDS operations of ONE wave on one array: the hardware runs them in program order and
-            // the compiler keeps may-aliasing accesses in order, so nothing else separates them (a fence here also pinned the next
-            // pair's operand reads behind this pair's reads).
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- dV / dK products; dS of the tile as [key c][queries 4g .. 4g+3 | 16 + 4g ..] -> staging rows 0..15 (a padded key's
+            // column holds whatever the zero K row produced; its K^T entries in `ka` are zero, so it adds nothing); the transposing
+            // reads are issued right behind the write.  Write, reads and the next pair's write are LDS operations of ONE wave on one
+            // array: the hardware runs them in program order and the compiler keeps may-aliasing accesses in order.
+            dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fo, pf, dv, 0, 0, 0);
+            dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq, dsf, dk, 0, 0, 0);
             *reinterpret_cast<uint2 *>(stg + c * TROW + (4 * g) * 2) = make_uint2(dw.x, dw.y);
             *reinterpret_cast<uint2 *>(stg + c * TROW + (16 + 4 * g) * 2) = make_uint2(dw.z, dw.w);
+            pmx_bf16x8 bT[2];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const char *a0 = stg + (8 * g + tr_row) * TROW + half * 32 + tr_pc * 8;
                 const pmx_bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pmx_bf16x4 __attribute__((address_space(3))) *)(a0));
                 const pmx_bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pmx_bf16x4 __attribute__((address_space(3))) *)(a0 + 4 * TROW));
-                const pmx_bf16x8 bT = { lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3] };
-                dq[2 * j + half] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, bT, dq[2 * j + half], 0, 0, 0);
+                bT[half] = pmx_bf16x8{ lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3] };
             }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- the next pair's score products run while the transposing reads come back
+            Sc nxt = cur;
+            if (more) nxt = score(j + 1, nxt_ops);
+            __builtin_amdgcn_sched_barrier(0);
+            dq[2 * j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, bT[0], dq[2 * j], 0, 0, 0);
+            dq[2 * j + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, bT[1], dq[2 * j + 1], 0, 0, 0);
+            cur = nxt;
         }
         if (QS > 1) {
             // the second wave's partial dK^T / dV^T tiles (its half of the queries) -> slot kt & 1; the first wave adds them after the

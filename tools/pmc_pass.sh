@@ -10,3 +10,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd $ROOT
 python tools/pmc_traffic.py /tmp/pmc_${TAG}_FETCH_SIZE /tmp/pmc_${TAG}_WRITE_SIZE $W:$O gpurun_out/traffic_new.json
+# the training loop's observation kernel (byte planes) runs in the same bench process (roofline_emit_team)
+python tools/pmc_traffic.py /tmp/pmc_${TAG}_FETCH_SIZE /tmp/pmc_${TAG}_WRITE_SIZE $W:emit_uint8 gpurun_out/traffic_new.json pmx_emit_team
