@@ -665,7 +665,7 @@ __global__ __launch_bounds__(256, 1) void pmx_actor_bwd_data_kernel(const char *
         // its affine parameters and statistics -- is loaded ONE LAYER AHEAD, into registers the loop carries (at one wave per
         // SIMD the file has room and nothing else hides a round trip to L2 / HBM).
         uint2 hp[NT][2], xg[NT][2];
-        float gw[2][4], gb[2][4], mean[2], rstd[2];
+        float gw[2][4], gb[2][4], mean[2], rstd[2], nmr[2];
         auto load_layer_inputs = [&](int ln) {
             const bool res_n = ln >= 3 && (ln & 1);
             const int lres = ln >= 2 ? ln - 2 : 0;
@@ -675,6 +675,7 @@ __global__ __launch_bounds__(256, 1) void pmx_actor_bwd_data_kernel(const char *
                 for (int r = 0; r < 4; ++r) gw[m][r] = gnwp[ln * 32 + 16 * m + 4 * g + r], gb[m][r] = gnbp[ln * 32 + 16 * m + 4 * g + r];
                 const float *st = stats + (((size_t)ln * B + s) * 4 + 2 * m + (g >> 1)) * 2;
                 mean[m] = st[0], rstd[m] = st[1];                  // (0, 1) for the layers without GroupNorm
+                nmr[m] = -mean[m] * rstd[m];
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -702,7 +703,7 @@ __global__ __launch_bounds__(256, 1) void pmx_actor_bwd_data_kernel(const char *
             asm volatile("" : "+s"(WPv));
             asm volatile("" : "+v"(pq), "+v"(vmk));
             // ---- pass 1: dz = dY GELU'(z), sums for the GroupNorm backward and for the affine gradients -----------------
-            float S1[2] = {0.f, 0.f}, S2[2] = {0.f, 0.f};
+            float S1[2], S2[2];
             float dgw[2][4], dgb[2][4];
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -728,7 +729,7 @@ __global__ __launch_bounds__(256, 1) void pmx_actor_bwd_data_kernel(const char *
                             float dzf[4], xh[4];
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                xh[r] = (hv[r] - mean[m]) * rstd[m];
+                                xh[r] = fmaf(hv[r], rstd[m], nmr[m]);
                                 const float z = xv[r] + fmaf(xh[r], gw[m][r], gb[m][r]);
                                 float e;
                                 const float phi = phi_cdf(z, e);
@@ -742,9 +743,6 @@ __global__ __launch_bounds__(256, 1) void pmx_actor_bwd_data_kernel(const char *
                             for (int r = 0; r < 4; ++r) {
                                 dgb[m][r] += dzr[r];
                                 dgw[m][r] = fmaf(dzr[r], xh[r], dgw[m][r]);
-                                const float gd = gw[m][r] * dzr[r];
-                                S1[m] += gd;
-                                S2[m] = fmaf(gd, xh[r], S2[m]);
                             }
                             __builtin_amdgcn_sched_barrier(0);
                         }
@@ -755,8 +753,21 @@ __global__ __launch_bounds__(256, 1) void pmx_actor_bwd_data_kernel(const char *
 #pragma unroll
                     for (int m = 0; m < 2; ++m) skp[(t * 2 + m) * 64] = dv[t][m];
             }
+            // The two sums of the GroupNorm backward are weighted sums of the per-channel sums the affine gradients need anyway:
+            // sum(gw dz) = sum_c gw_c dgb_c, sum(gw dz xhat) = sum_c gw_c dgw_c (the sample's, before they join the wave's totals).
+            // dh = rstd (gw dz - S1 - xhat S2) then is two fused multiply-adds per element: A dz + (K2 h + K3).
+            float Ad[2][4], K2[2], K3[2];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) S1[m] = group_sum(S1[m]) * inv_n * gn_on, S2[m] = group_sum(S2[m]) * inv_n * gn_on;
+            for (int m = 0; m < 2; ++m) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t1 = fmaf(gw[m][r], dgb[m][r], t1), t2 = fmaf(gw[m][r], dgw[m][r], t2);
+                S1[m] = group_sum(t1) * inv_n * gn_on, S2[m] = group_sum(t2) * inv_n * gn_on;
+                K2[m] = -rstd[m] * rstd[m] * S2[m];
+                K3[m] = -mean[m] * K2[m] - rstd[m] * S1[m];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ad[m][r] = rstd[m] * gw[m][r];
+            }
             wave_lds_fence();
             // the flipped weights of the input-gradient convolution: needed after pass 2, asked for now
             // ---- pass 2: dh, into the map (for the input gradient) ---------------------------------------------------------
@@ -776,10 +787,7 @@ __global__ __launch_bounds__(256, 1) void pmx_actor_bwd_data_kernel(const char *
                     const float dzr[4] = {lo_f(dv[t][m].x), hi_f(dv[t][m].x), lo_f(dv[t][m].y), hi_f(dv[t][m].y)};
                     float dh[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float xh = (hv[r] - mean[m]) * rstd[m];
-                        dh[r] = vm * rstd[m] * (gw[m][r] * dzr[r] - S1[m] - xh * S2[m]);
-                    }
+                    for (int r = 0; r < 4; ++r) dh[r] = vm * fmaf(Ad[m][r], dzr[r], fmaf(hv[r], K2[m], K3[m]));
                     const uint2 d2 = {pack2(dh[0], dh[1]), pack2(dh[2], dh[3])};
                     // the bias gradient sums what the matrix cores see (the bf16-rounded dh), like autograd on a bf16 tensor
                     dbias[m][0] += lo_f(d2.x), dbias[m][1] += hi_f(d2.x), dbias[m][2] += lo_f(d2.y), dbias[m][3] += hi_f(d2.y);
@@ -940,7 +948,7 @@ __global__ __launch_bounds__(256, WS == 4 ? 2 : 1) void pmx_actor_bwd_data_split
             }
         }
         uint2 hp[NTW][2], xg[NTW][2];
-        float gw[2][4], gb[2][4], mean[2], rstd[2];
+        float gw[2][4], gb[2][4], mean[2], rstd[2], nmr[2];
         auto load_layer_inputs = [&](int ln) {
             const bool res_n = ln >= 3 && (ln & 1);
             const int lres = ln >= 2 ? ln - 2 : 0;
@@ -950,6 +958,7 @@ __global__ __launch_bounds__(256, WS == 4 ? 2 : 1) void pmx_actor_bwd_data_split
                 for (int r = 0; r < 4; ++r) gw[m][r] = gnwp[ln * 32 + 16 * m + 4 * g + r], gb[m][r] = gnbp[ln * 32 + 16 * m + 4 * g + r];
                 const float *st = stats + (((size_t)ln * B + s) * 4 + 2 * m + (g >> 1)) * 2;
                 mean[m] = st[0], rstd[m] = st[1];
+                nmr[m] = -mean[m] * rstd[m];
             }
 #pragma unroll
             for (int tl = 0; tl < NTW; ++tl)
@@ -984,7 +993,7 @@ __global__ __launch_bounds__(256, WS == 4 ? 2 : 1) void pmx_actor_bwd_data_split
                     }
             }
             // ---- pass 1 on the own tiles ---------------------------------------------------------------------------------
-            float S1[2] = {0.f, 0.f}, S2[2] = {0.f, 0.f};
+            float S1[2], S2[2];
             float dgw[2][4], dgb[2][4];
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -1002,7 +1011,7 @@ __global__ __launch_bounds__(256, WS == 4 ? 2 : 1) void pmx_actor_bwd_data_split
                         float dzf[4], xh[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            xh[r] = (hv[r] - mean[m]) * rstd[m];
+                            xh[r] = fmaf(hv[r], rstd[m], nmr[m]);
                             const float z = xv[r] + fmaf(xh[r], gw[m][r], gb[m][r]);
                             float e;
                             const float phi = phi_cdf(z, e);
@@ -1016,9 +1025,6 @@ __global__ __launch_bounds__(256, WS == 4 ? 2 : 1) void pmx_actor_bwd_data_split
                         for (int r = 0; r < 4; ++r) {
                             dgb[m][r] += dzr[r];
                             dgw[m][r] = fmaf(dzr[r], xh[r], dgw[m][r]);
-                            const float gd = gw[m][r] * dzr[r];
-                            S1[m] += gd;
-                            S2[m] = fmaf(gd, xh[r], S2[m]);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -1035,7 +1041,11 @@ __global__ __launch_bounds__(256, WS == 4 ? 2 : 1) void pmx_actor_bwd_data_split
             // the wave's partial sums of the four groups -> LDS; after the barrier every wave adds all of them
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                const float a1 = group_sum(S1[m]), a2 = group_sum(S2[m]);
+                // (sum(gw dz) and sum(gw dz xhat) as weighted sums of the per-channel sums: see pmx_actor_bwd_data_kernel)
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t1 = fmaf(gw[m][r], dgb[m][r], t1), t2 = fmaf(gw[m][r], dgw[m][r], t2);
+                const float a1 = group_sum(t1), a2 = group_sum(t2);
                 if (p == 0 && (g & 1) == 0) {
                     xs[(wq * 4 + 2 * m + (g >> 1)) * 2] = a1;
                     xs[(wq * 4 + 2 * m + (g >> 1)) * 2 + 1] = a2;
@@ -1053,6 +1063,14 @@ __global__ __launch_bounds__(256, WS == 4 ? 2 : 1) void pmx_actor_bwd_data_split
 #pragma unroll
                 for (int w = 0; w < WS; ++w) { a1 += xs[(w * 4 + grp) * 2]; a2 += xs[(w * 4 + grp) * 2 + 1]; }
                 S1[m] = a1 * inv_n * gn_on, S2[m] = a2 * inv_n * gn_on;
+            }
+            float Ad[2][4], K2[2], K3[2];                       // dh = A dz + (K2 h + K3)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                K2[m] = -rstd[m] * rstd[m] * S2[m];
+                K3[m] = -mean[m] * K2[m] - rstd[m] * S1[m];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ad[m][r] = rstd[m] * gw[m][r];
             }
             // ---- pass 2: dh of the own tiles into the shared map ----------------------------------------------------------
             float dbias[2][4];
@@ -1073,10 +1091,7 @@ __global__ __launch_bounds__(256, WS == 4 ? 2 : 1) void pmx_actor_bwd_data_split
                         const float dzr[4] = {lo_f(dv[tl][m].x), hi_f(dv[tl][m].x), lo_f(dv[tl][m].y), hi_f(dv[tl][m].y)};
                         float dh[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float xh = (hv[r] - mean[m]) * rstd[m];
-                            dh[r] = vm * rstd[m] * (gw[m][r] * dzr[r] - S1[m] - xh * S2[m]);
-                        }
+                        for (int r = 0; r < 4; ++r) dh[r] = vm * fmaf(Ad[m][r], dzr[r], fmaf(hv[r], K2[m], K3[m]));
                         const uint2 d2 = {pack2(dh[0], dh[1]), pack2(dh[2], dh[3])};
                         dbias[m][0] += lo_f(d2.x), dbias[m][1] += hi_f(d2.x), dbias[m][2] += lo_f(d2.y), dbias[m][3] += hi_f(d2.y);
                         *reinterpret_cast<uint2 *>(wbase + (WPv + 16 * t) * 64 + m * 32) = d2;

@@ -237,12 +237,22 @@ __device__ __forceinline__ void pool8(const __hip_bfloat16 *tok, int S, int lane
 }
 
 // w1t: the first layer's weight transposed and rounded to bf16, as float32 [32][512] in LDS (a lane reads 8 consecutive hidden units
-// of one input feature: two conflict-free 16-byte reads)
+// of one input feature: two conflict-free 16-byte reads).  A thread carries whole rows of w1 (128 contiguous bytes, 8 loads of 16) and
+// writes them down a column: for a fixed k consecutive threads write consecutive words (the first version walked w1 linearly and
+// wrote with a stride of 512 words -- every store of a wave on ONE bank: 27 us for a kernel with 10 us of work).
 __device__ __forceinline__ void stage_w1t(const float *__restrict__ w1, float *w1t)
 {
-    for (int i = threadIdx.x; i < HID * DM; i += 256) {
-        const int j = i >> 5, k = i & 31;                              // w1[j][k], coalesced read
-        w1t[k * HID + j] = bf_round(w1[i]);
+    for (int j = threadIdx.x; j < HID; j += 256) {
+        float4 r[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r[q] = reinterpret_cast<const float4 *>(w1 + (size_t)j * DM)[q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            w1t[(4 * q + 0) * HID + j] = bf_round(r[q].x);
+            w1t[(4 * q + 1) * HID + j] = bf_round(r[q].y);
+            w1t[(4 * q + 2) * HID + j] = bf_round(r[q].z);
+            w1t[(4 * q + 3) * HID + j] = bf_round(r[q].w);
+        }
     }
 }
 
@@ -362,8 +372,8 @@ __global__ __launch_bounds__(256) void pmx_critic_tail_bwd_kernel(const float *_
 // parameter gradients of the critic tail from dh, g [B][512] bf16, pooled [B][32], dvalue [B]: block (x, y) owns 8 hidden units and a
 // chunk of the batch, thread (unit, k) walks the chunk: dW1[j][k] = sum_b dh[b][j] pooled[b][k]; the k = 0 / 1 threads also carry
 // db1[j] = sum_b dh[b][j] and dw2[j] = sum_b dv[b] g[b][j]; blocks x = 0 add db2 = sum_b dv[b].  One chunk: the sums go straight to
-// row 0; several: to partial rows 1 + y, and the row-sum kernel follows.  (A thread's loop is a chain of dependent-latency-bound
-// iterations -- about 0.25 us each -- so a chunk is at most 256 samples.)
+// row 0; several: to partial rows 1 + y, and the row-sum kernel follows.  (A thread's loop is a chain of load round trips, so the
+// chunks are short -- 16 samples up to 2 048, B / 128 beyond -- and the blocks many: one 256-sample chunk took 80 us.)
 __global__ __launch_bounds__(256) void pmx_critic_tail_wgrad_kernel(const __hip_bfloat16 *__restrict__ dh, const __hip_bfloat16 *__restrict__ g,
                                                                    const float *__restrict__ pooled, const float *__restrict__ dvalue,
                                                                    float *__restrict__ grad, int B, int chunk, int single)
@@ -482,7 +492,8 @@ extern "C" int pmx_critic_tail_backward(const float *pooled_dev, const float *dv
     if (rc) return rc;
     hipLaunchKernelGGL(pmx_critic_tail_bwd_kernel, dim3(heads_blocks(B, 512)), dim3(256), lds, st, pooled_dev, dvalue_dev, w1, b1, w2,
                        (__hip_bfloat16 *)dtokens_dev, dh, g, (int)B, (int)S);
-    int64_t chunk = 256;
+    // a thread's walk over its chunk is a chain of load round trips (~0.3 us per 4 samples at these sizes): short chunks, many blocks
+    int64_t chunk = 16;
     if ((B + chunk - 1) / chunk > PMX_HEADS_PARTIAL_ROWS) chunk = (B + PMX_HEADS_PARTIAL_ROWS - 1) / PMX_HEADS_PARTIAL_ROWS;
     const int n_chunks = (int)((B + chunk - 1) / chunk);
     hipLaunchKernelGGL(pmx_critic_tail_wgrad_kernel, dim3(HID / 8, n_chunks), dim3(256), 0, st, (const __hip_bfloat16 *)dh, (const __hip_bfloat16 *)g,
