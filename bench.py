@@ -187,7 +187,9 @@ def e2e_probe(layout, dev, rank, world, dist, n_envs, horizon, minibatch, use_gr
     grad_bytes = tr.learner.bucket.grad.numel() * 4
     fused = bool(tr.model._use_fused_tower(tr.obs_buf[0, :1, 0]))
     graphs = 0 if not tr.use_graph else (len(tr.learner._graphs) if tr.learner._graphs else 1)
-    groups = [int(tr.learner._offsets[hi] - tr.learner._offsets[lo]) * 4 for lo, hi in tr.learner._grad_groups()] if dp else []
+    L = tr.learner
+    eager_groups = L._grad_groups() if dp else []
+    groups = [int(L._offsets[hi] - L._offsets[lo]) * 4 for lo, hi in (L._g_groups if (dp and L._graphs) else eager_groups)] if dp else []
     tr.env.close()
     del tr
     torch.cuda.empty_cache()
@@ -198,8 +200,11 @@ def e2e_probe(layout, dev, rank, world, dist, n_envs, horizon, minibatch, use_gr
             "train_samples_per_s": steps * minibatch * world / t_upd, "hipgraph_replay": bool(graphs), "hipgraphs_per_step": graphs,
             "finite": finite, "fused_actor_tower": fused,
             "grad_allreduce": (f"RCCL all-reduce (mean) of the flat fp32 gradient bucket ({grad_bytes / 1e6:.1f} MB) per optimizer step in "
-                               f"{len(groups)} slices of {[round(g / 1e6, 2) for g in groups]} MB (actor first, in flight during the critic's "
-                               f"backward)" + (" -- ONE-rank rehearsal" if world == 1 else "")) if dp else "none (1 GPU)"}
+                               f"{len(groups)} slice(s) of {[round(g / 1e6, 2) for g in groups]} MB"
+                               + (" (actor first, in flight during the critic's backward)" if len(groups) > 1 else
+                                  " between the [forward + backward] graph and the [optimizer] graph (actor and critic halves run side by "
+                                  "side on two streams inside the first)")
+                               + (" -- ONE-rank rehearsal" if world == 1 else "")) if dp else "none (1 GPU)"}
 
 
 NETWORK_NOTE = ("MAPPOAgent: actor tower = one fused HIP forward kernel + two backward kernels on bf16 MFMA (csrc/pmx_actor.hip; boards of 10, "
