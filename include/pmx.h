@@ -398,6 +398,38 @@ int pmx_critic_tail_forward(const void *tokens_dev, const float *w1, const float
 int pmx_critic_tail_backward(const float *pooled_dev, const float *dvalue_dev, const float *w1, const float *b1, const float *w2,
                              void *dtokens_dev, void *scratch_dev, float *grad_dev, int64_t B, int32_t S, void *stream);
 
+/* All parameter packs of up to four encoder layers in one launch (what pmx_tok96_pack, pmx_tok32ln_pack and pmx_ffn_pack produce, into
+ * the three pack buffers of each layer). */
+typedef struct {
+    const float *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b, *norm1_w, *norm1_b;     /* [96][32], [96], [32][32], [32], [32], [32] */
+    const float *lin1_w, *lin1_b, *lin2_w, *lin2_b, *norm2_w, *norm2_b;                   /* [128][32], [128], [32][128], [32], [32], [32] */
+    void *pack_in, *pack_out, *pack_ffn;    /* PMX_TOK96_PACK_BYTES, PMX_TOK32_PACK_BYTES, PMX_FFN_PACK_BYTES */
+} pmx_encoder_layer_params;
+int pmx_encoder_pack(int32_t n_layers, const pmx_encoder_layer_params *layers, void *stream);
+
+/* ---- The critic's projector: conv3x3(8 -> 32) + bias + 2-D positional encoding -> batch-major tokens ---------------------
+ * MAPPOAgent.critic_projector and pos_encoder (pacman_mappo_resnet.py:126-127, :69-95, :164) on boards pmx_actor_supported() accepts:
+ * obs_dev [B][8][H][W] of PMX_OBS_* elements -> tokens_dev [B][H*W][32] bfloat16 (what flatten(2).permute(2, 0, 1) yields, batch-major),
+ * bf16 products with fp32 accumulation, the convolution (+ bias) rounded to bfloat16 before the table (posenc_dev [H*W][32] float32) is
+ * added in bfloat16, as autocast computes it.  Backward returns the weight and bias gradients only (the observations need none):
+ * dw_dev [32][8][3][3], db_dev [32] float32; partial_dev is scratch of PMX_PROJ_PARTIAL_ROWS x PMX_PROJ_GRAD_ROW_FLOATS floats. */
+#define PMX_PROJ_PACK_BYTES 6272
+#define PMX_PROJ_PARTIAL_ROWS 256
+#define PMX_PROJ_GRAD_ROW_FLOATS 2592
+int pmx_proj_pack(const float *w, const float *b, void *pack_dev, void *stream);
+int pmx_proj_forward(const void *obs_dev, int32_t obs_dtype, const void *pack_dev, const float *posenc_dev, void *tokens_dev, int64_t B,
+                     int32_t H, int32_t W, void *stream);
+int pmx_proj_backward(const void *obs_dev, int32_t obs_dtype, const void *dtokens_dev, float *partial_dev, float *dw_dev, float *db_dev,
+                      int64_t B, int32_t H, int32_t W, void *stream);
+
+/* Deferred row sums (per host thread).  The backward entry points of the pmx_ffn / pmx_tok96 / pmx_tok32ln / pmx_actor_tail / pmx_critic_tail
+ * families end with a small second-stage kernel that adds their partial rows into row 0 of grad_dev.  After pmx_defer_row_sums(1) they
+ * skip it; pmx_last_partial_rows() then tells how many rows the last such call left (0: row 0 is already final), and the caller adds them
+ * with pmx_sum_partial_rows(grad_dev, rows, floats-per-row, stream) -- on a side stream, beside the next backward kernel. */
+int pmx_defer_row_sums(int32_t on);
+int pmx_last_partial_rows(void);
+int pmx_sum_partial_rows(float *buf_dev, int32_t n_rows, int32_t floats, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,7 @@ FFN_GRAD_FLOATS = 8416
 TOK96_PACK_BYTES, TOK96_GRAD_FLOATS = 12928, 3232
 TOK32_PACK_BYTES, TOK32_GRAD_FLOATS = 4480, 1120
 HEADS_PARTIAL_ROWS, ACTOR_TAIL_GRAD_FLOATS, CRITIC_TAIL_GRAD_FLOATS = 128, 3592, 17416
+PROJ_PACK_BYTES, PROJ_PARTIAL_ROWS, PROJ_GRAD_ROW_FLOATS = 6272, 256, 2592
 
 
 class PmxError(RuntimeError):
@@ -51,6 +52,11 @@ class State(C.Structure):
 
 class ActorParams(C.Structure):
     _fields_ = [("conv_w", C.c_void_p * 8), ("conv_b", C.c_void_p * 8), ("gn_w", C.c_void_p * 6), ("gn_b", C.c_void_p * 6)]
+
+
+class EncoderLayerParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "norm1_w", "norm1_b", "lin1_w", "lin1_b",
+                                          "lin2_w", "lin2_b", "norm2_w", "norm2_b", "pack_in", "pack_out", "pack_ffn")]
 
 
 # every symbol include/pmx.h declares: (name, restype, argtypes)
@@ -114,6 +120,13 @@ PROTOTYPES = [
     ("pmx_actor_tail_backward", C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
     ("pmx_critic_tail_forward", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _I32, _VP]),
     ("pmx_critic_tail_backward", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _I32, _VP]),
+    ("pmx_encoder_pack", C.c_int, [_I32, C.POINTER(EncoderLayerParams), _VP]),
+    ("pmx_proj_pack", C.c_int, [_VP, _VP, _VP, _VP]),
+    ("pmx_proj_forward", C.c_int, [_VP, _I32, _VP, _VP, _VP, C.c_int64, _I32, _I32, _VP]),
+    ("pmx_proj_backward", C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, C.c_int64, _I32, _I32, _VP]),
+    ("pmx_defer_row_sums", C.c_int, [_I32]),
+    ("pmx_last_partial_rows", C.c_int, []),
+    ("pmx_sum_partial_rows", C.c_int, [_VP, _I32, _I32, _VP]),
 ]
 # test / bench hooks that are not part of the public header
 EXTRA = [

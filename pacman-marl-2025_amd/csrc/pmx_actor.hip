@@ -1767,6 +1767,295 @@ extern "C" int pmx_actor_backward(const void *obs_dev, int32_t obs_dtype, const 
 #undef PMX_BWD
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The critic's projector (pacman_mappo_resnet.py:126-127 critic_projector + :69-95 / :164 the positional encoding): conv3x3(8 -> 32)
+// + bias + position table -> the token tensor [B][H*W][32] bf16 the batch-major encoder reads -- straight from the observation
+// planes (bytes as they are), with the map machinery of the tower above.  Only 8 input channels exist, so the K = 32 of the matrix
+// instruction is filled with the THREE taps of a kernel row: lane group g < 3 reads the 8 channels of the position shifted by
+// g - 1 (one ds_read_b128 per lane, the address is the lane's own) and the A operand holds w[co][ci][ky][kx = g] in k-slots
+// 8 g + ci -- 6 matrix instructions per 16 positions instead of 18.  The weight gradient contracts over positions: A = dTok^T
+// and B = the shifted input through transposing reads, TWO taps per 16-column tile (columns 8 s + ci, each half of the reading
+// lanes pointing at its own shift): 5 tap pairs x 2 output halves = 10 instructions per 32 positions.  The input needs no gradient.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int PROJ_FRAG = 2 * 3 * 64 * 8;                           // bf16 elements of the forward fragments: [m][ky][lane][8]
+constexpr size_t PROJ_PACK_BIAS = (size_t)PROJ_FRAG * 2;
+constexpr size_t PROJ_PACK_BYTES_C = PROJ_PACK_BIAS + 32 * 4;
+static_assert(PROJ_PACK_BYTES_C == PMX_PROJ_PACK_BYTES, "include/pmx.h and pmx_actor.hip disagree on the projector pack size");
+constexpr int PROJ_GRAD_TILES = 10, PROJ_ROW = PROJ_GRAD_TILES * 256 + 32;      // [pair 5][mo 2] tiles of 64 lanes x 4, then db[32]
+static_assert(PROJ_ROW == PMX_PROJ_GRAD_ROW_FLOATS, "include/pmx.h and pmx_actor.hip disagree on the projector gradient row");
+
+__global__ __launch_bounds__(256) void pmx_proj_pack_kernel(const float *__restrict__ w, const float *__restrict__ b, char *__restrict__ pack)
+{
+    short *fw = reinterpret_cast<short *>(pack);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < PROJ_FRAG; i += gridDim.x * 256) {
+        const int j = i & 7, lane = (i >> 3) & 63, ky = (i >> 9) % 3, m = i / (512 * 3);
+        const int co = 16 * m + (lane & 15), kx = lane >> 4;                    // k-slot 8 kx + j = (tap kx of the row, input channel j)
+        const float v = kx < 3 ? w[((size_t)co * 8 + j) * 9 + ky * 3 + kx] : 0.f;
+        fw[i] = (short)(pack2(v, 0.f) & 0xFFFF);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 32) reinterpret_cast<float *>(pack + PROJ_PACK_BIAS)[threadIdx.x] = b[threadIdx.x];
+}
+
+template <int NT, typename IN_T, int WPB>
+__global__ __launch_bounds__(64 * WPB) void pmx_proj_fwd_kernel(const IN_T *__restrict__ obs, const char *__restrict__ pack,
+                                                                const float *__restrict__ pe, uint2 *__restrict__ tok, int B, int H, int W)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = lane & 15, g = lane >> 4;
+    Geom G;
+    G.H = H, G.W = W, G.WP = W + 2, G.HW = H * W, G.MP = map_positions(NT, W + 2);
+    char *map = smem + (size_t)wave * G.MP * 64;
+    for (int i = lane; i < G.MP * 4; i += 64) reinterpret_cast<uint4 *>(map)[i] = uint4{0, 0, 0, 0};
+    __shared__ int cell_tab[NT * 16];
+    for (int i = threadIdx.x; i < NT * 16; i += 64 * WPB) {
+        const int q = G.WP + i, row = q / G.WP, col = q - row * G.WP;
+        cell_tab[i] = (col >= 1 && col <= W && row <= H) ? (row - 1) * W + (col - 1) : -1;
+    }
+    __syncthreads();
+    bf16x8 A[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) A[m][ky] = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const short *>(pack) + ((m * 3 + ky) * 64 + lane) * 8);
+    float bias[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[m][r] = reinterpret_cast<const float *>(pack + PROJ_PACK_BIAS)[16 * m + 4 * g + r];
+    // lane group g reads the position shifted by g - 1 (group 3: any finite operand, its k-slots meet zero weights)
+    const char *rbase = map + (p + GUARD + (g < 3 ? g - 1 : 0)) * 64;
+    for (int s = blockIdx.x * WPB + wave; s < B; s += gridDim.x * WPB) {
+        wave_lds_fence();
+        load_obs<IN_T>(obs + (size_t)s * 8 * G.HW, map, G, lane);
+        wave_lds_fence();
+#pragma unroll 2
+        for (int t = 0; t < NT; ++t) {
+            f32x4 a[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8 *>(rbase + (G.WP + 16 * t + (ky - 1) * G.WP) * 64);
+                a[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0][ky], b, a[0], 0, 0, 0);
+                a[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1][ky], b, a[1], 0, 0, 0);
+            }
+            const int ci = cell_tab[16 * t + p];
+            if (ci >= 0) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const float4 e = *reinterpret_cast<const float4 *>(pe + (size_t)ci * 32 + 16 * m + 4 * g);
+                    // what bf16 autocast computes: the convolution (+ bias) rounded to bf16, then the bf16 sum with the bf16 table
+                    const uint2 c2 = {pack2(a[m][0] + bias[m][0], a[m][1] + bias[m][1]), pack2(a[m][2] + bias[m][2], a[m][3] + bias[m][3])};
+                    const uint2 e2 = {pack2(e.x, e.y), pack2(e.z, e.w)};
+                    const uint2 y2 = {pack2(lo_f(c2.x) + lo_f(e2.x), hi_f(c2.x) + hi_f(e2.x)), pack2(lo_f(c2.y) + lo_f(e2.y), hi_f(c2.y) + hi_f(e2.y))};
+                    tok[((size_t)s * G.HW + ci) * 8 + 4 * m + g] = y2;
+                }
+            }
+        }
+    }
+}
+
+// weight / bias gradient: a block walks its samples one at a time -- all waves copy the sample's dTok rows and planes into the two
+// maps, wave w then multiplies the key-pair blocks ks = w, w + 4, ..; 10 accumulator tiles per wave over the block's samples
+template <int NT, typename IN_T>
+__global__ __launch_bounds__(256, 2) void pmx_proj_wgrad_kernel(const IN_T *__restrict__ obs, const uint4 *__restrict__ dtok, float *__restrict__ part,
+                                                                int B, int H, int W, int per_block)
+{
+    constexpr int KS = (NT + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ unsigned short pos_tab[1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4;
+    Geom G;
+    G.H = H, G.W = W, G.WP = W + 2, G.HW = H * W, G.MP = map_positions(NT, W + 2);
+    char *mapX = smem, *mapD = smem + (size_t)G.MP * 64;
+    for (int i = threadIdx.x; i < 2 * G.MP * 4; i += 256) reinterpret_cast<uint4 *>(smem)[i] = uint4{0, 0, 0, 0};
+    for (int i = threadIdx.x; i < G.HW; i += 256) {
+        const int row = i / W, col = i - row * W;
+        pos_tab[i] = (unsigned short)((row + 1) * G.WP + col + 1 + GUARD);
+    }
+    __syncthreads();
+    f32x4 acc[PROJ_GRAD_TILES];
+#pragma unroll
+    for (int i = 0; i < PROJ_GRAD_TILES; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float db[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // channels 8 (tid & 3) .. + 7, summed over the rows this thread copies
+    const int tr_row = (lane & 15) >> 2, tr_pc = lane & 3;
+    const int s0 = blockIdx.x * per_block, s1 = s0 + per_block < B ? s0 + per_block : B;
+    for (int s = s0; s < s1; ++s) {
+        __syncthreads();                                            // the previous sample's reads are done
+        load_obs_block<IN_T>(obs + (size_t)s * 8 * G.HW, mapX, G, threadIdx.x, 256);
+        for (int i = threadIdx.x; i < G.HW * 4; i += 256) {
+            const uint4 u = dtok[(size_t)s * G.HW * 4 + i];
+            *reinterpret_cast<uint4 *>(mapD + (size_t)pos_tab[i >> 2] * 64 + (i & 3) * 16) = u;
+            db[0] += lo_f(u.x), db[1] += hi_f(u.x), db[2] += lo_f(u.y), db[3] += hi_f(u.y);
+            db[4] += lo_f(u.z), db[5] += hi_f(u.z), db[6] += lo_f(u.w), db[7] += hi_f(u.w);
+        }
+        __syncthreads();
+        for (int ks = wave; ks < KS; ks += 4) {
+            const int q0 = G.WP + 32 * ks + 8 * g + tr_row + GUARD;             // the lane's row of a transposing read
+            bf16x8 Ad[2];
+#pragma unroll
+            for (int mo = 0; mo < 2; ++mo) {
+                const char *a0 = mapD + q0 * 64 + mo * 32 + tr_pc * 8;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)(a0));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)(a0 + 256));
+                Ad[mo] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int pr = 0; pr < 5; ++pr) {
+                // columns 0..7 = tap 2 pr (read by the lanes with tr_pc < 2), 8..15 = tap 2 pr + 1 (tr_pc >= 2; the tenth tap does
+                // not exist: those lanes re-read tap 8, its columns are dropped when the gradient is unpacked)
+                const int tap = 2 * pr + (tr_pc >> 1) < 9 ? 2 * pr + (tr_pc >> 1) : 8;
+                const int sh = (tap / 3 - 1) * G.WP + (tap % 3 - 1);
+                const char *b0 = mapX + (q0 + sh) * 64 + (tr_pc & 1) * 8;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)(b0));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)(b0 + 256));
+                const bf16x8 Bx = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                acc[pr * 2 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ad[0], Bx, acc[pr * 2 + 0], 0, 0, 0);
+                acc[pr * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ad[1], Bx, acc[pr * 2 + 1], 0, 0, 0);
+            }
+        }
+    }
+    // block sum of the four waves' tiles and of the 256 threads' bias sums -> the block's partial row
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem);                  // 4 x 10 x 256 floats = 40 KB (the launch reserves at least that)
+#pragma unroll
+    for (int i = 0; i < PROJ_GRAD_TILES; ++i) *reinterpret_cast<f32x4 *>(red + ((size_t)(wave * PROJ_GRAD_TILES + i) * 64 + lane) * 4) = acc[i];
+    __syncthreads();
+    float *row = part + (size_t)blockIdx.x * PROJ_ROW;
+    for (int i = threadIdx.x; i < PROJ_GRAD_TILES * 256; i += 256)
+        row[i] = (red[i] + red[PROJ_GRAD_TILES * 256 + i]) + (red[2 * PROJ_GRAD_TILES * 256 + i] + red[3 * PROJ_GRAD_TILES * 256 + i]);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = db[i];
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int chunk = threadIdx.x >> 3, i = threadIdx.x & 7;
+        float t = 0.f;
+        for (int k = chunk; k < 256; k += 4) t += red[k * 8 + i];
+        row[PROJ_GRAD_TILES * 256 + threadIdx.x] = t;
+    }
+}
+
+// rows -> dW [32][8][3][3] and db [32] in the parameters' own layout (the row sum and the unpacking in one launch): 32 outputs x 8
+// row slices per block, slices added through LDS (one thread per output walking all the rows alone is a chain of load round trips)
+__global__ __launch_bounds__(256) void pmx_proj_sum_kernel(const float *__restrict__ part, int n_rows, float *__restrict__ dw, float *__restrict__ dbias)
+{
+    __shared__ float red[8][33];
+    const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + c;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < 32 * 72 + 32) {
+        size_t src;
+        if (i < 32 * 72) {
+            const int co = i / 72, rem = i - co * 72, ci = rem / 9, tap = rem - ci * 9;
+            const int pr = tap >> 1, n = (tap & 1) * 8 + ci, mo = co >> 4, gg = (co & 15) >> 2, r = co & 3;
+            src = (size_t)(pr * 2 + mo) * 256 + (size_t)(gg * 16 + n) * 4 + r;
+        } else {
+            src = (size_t)PROJ_GRAD_TILES * 256 + (i - 32 * 72);
+        }
+        int k = sl;
+        for (; k + 24 < n_rows; k += 32) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] += part[(size_t)(k + 8 * u) * PROJ_ROW + src];
+        }
+        for (; k < n_rows; k += 8) acc[0] += part[(size_t)k * PROJ_ROW + src];
+    }
+    red[sl][c] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (sl == 0 && i < 32 * 72 + 32) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][c];
+        if (i < 32 * 72) dw[i] = t; else dbias[i - 32 * 72] = t;
+    }
+}
+
+template <int NT, typename IN_T>
+int launch_proj_fwd(const void *obs, const void *pack, const float *pe, void *tok, int64_t B, int H, int W, hipStream_t st)
+{
+    constexpr int WPB = large_board(NT) ? 2 : 4;
+    const size_t lds = (size_t)WPB * map_positions(NT, W + 2) * 64;
+    int rc = allow_lds(pmx_proj_fwd_kernel<NT, IN_T, WPB>, lds);
+    if (rc) return rc;
+    int64_t want = (B + WPB - 1) / WPB, cap = 256 * 8;
+    hipLaunchKernelGGL((pmx_proj_fwd_kernel<NT, IN_T, WPB>), dim3((unsigned)(want < cap ? want : cap)), dim3(64 * WPB), lds, st, (const IN_T *)obs,
+                       (const char *)pack, pe, (uint2 *)tok, (int)B, H, W);
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
+
+template <int NT, typename IN_T>
+int launch_proj_bwd(const void *obs, const void *dtok, float *part, float *dw, float *db, int64_t B, int H, int W, hipStream_t st)
+{
+    const size_t maps = (size_t)2 * map_positions(NT, W + 2) * 64, scratch = (size_t)4 * PROJ_GRAD_TILES * 256 * 4;
+    const size_t lds = maps > scratch ? maps : scratch;            // the block-sum scratch reuses the maps' space (40 KB at least)
+    int rc = allow_lds(pmx_proj_wgrad_kernel<NT, IN_T>, lds);
+    if (rc) return rc;
+    int64_t blocks = B < PMX_PROJ_PARTIAL_ROWS ? B : PMX_PROJ_PARTIAL_ROWS;
+    const int64_t per_block = (B + blocks - 1) / blocks;
+    blocks = (B + per_block - 1) / per_block;
+    hipLaunchKernelGGL((pmx_proj_wgrad_kernel<NT, IN_T>), dim3((unsigned)blocks), dim3(256), lds, st, (const IN_T *)obs, (const uint4 *)dtok, part,
+                       (int)B, H, W, (int)per_block);
+    hipLaunchKernelGGL(pmx_proj_sum_kernel, dim3((32 * 72 + 32 + 31) / 32), dim3(256), 0, st, (const float *)part, (int)blocks, dw, db);
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
+
+}   // namespace
+
+extern "C" int pmx_proj_pack(const float *w, const float *b, void *pack_dev, void *stream)
+{
+    if (!w || !b || !pack_dev) return PMX_ERR_INVALID;
+    hipLaunchKernelGGL(pmx_proj_pack_kernel, dim3(6), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, b, reinterpret_cast<char *>(pack_dev));
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
+
+extern "C" int pmx_proj_forward(const void *obs_dev, int32_t obs_dtype, const void *pack_dev, const float *posenc_dev, void *tokens_dev, int64_t B,
+                                int32_t H, int32_t W, void *stream)
+{
+    if (B == 0) return pmx_actor_supported(H, W) ? PMX_OK : PMX_ERR_UNSUPPORTED;
+    if (!obs_dev || !pack_dev || !posenc_dev || !tokens_dev || B < 0) return PMX_ERR_INVALID;
+    if (!pmx_actor_supported(H, W)) return PMX_ERR_UNSUPPORTED;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int nt = tiles_for(H, W);
+#define PMX_PF(NT)                                                                                                        \
+    switch (obs_dtype) {                                                                                                  \
+    case PMX_OBS_F32: return launch_proj_fwd<NT, float>(obs_dev, pack_dev, posenc_dev, tokens_dev, B, H, W, st);              \
+    case PMX_OBS_BF16: return launch_proj_fwd<NT, __hip_bfloat16>(obs_dev, pack_dev, posenc_dev, tokens_dev, B, H, W, st);    \
+    case PMX_OBS_U8: return launch_proj_fwd<NT, uint8_t>(obs_dev, pack_dev, posenc_dev, tokens_dev, B, H, W, st);             \
+    default: return PMX_ERR_INVALID;                                                                                      \
+    }
+    if (nt == 10) { PMX_PF(10) }
+    if (nt == 28) { PMX_PF(28) }
+    PMX_PF(11)
+#undef PMX_PF
+}
+
+extern "C" int pmx_proj_backward(const void *obs_dev, int32_t obs_dtype, const void *dtokens_dev, float *partial_dev, float *dw_dev, float *db_dev,
+                                 int64_t B, int32_t H, int32_t W, void *stream)
+{
+    if (!dw_dev || !db_dev || B < 0) return PMX_ERR_INVALID;
+    if (!pmx_actor_supported(H, W)) return PMX_ERR_UNSUPPORTED;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (B == 0) {
+        if (hipMemsetAsync(dw_dev, 0, sizeof(float) * 32 * 72, st) != hipSuccess || hipMemsetAsync(db_dev, 0, sizeof(float) * 32, st) != hipSuccess) return PMX_ERR_HIP;
+        return PMX_OK;
+    }
+    if (!obs_dev || !dtokens_dev || !partial_dev) return PMX_ERR_INVALID;
+    const int nt = tiles_for(H, W);
+#define PMX_PB(NT)                                                                                                                  \
+    switch (obs_dtype) {                                                                                                            \
+    case PMX_OBS_F32: return launch_proj_bwd<NT, float>(obs_dev, dtokens_dev, partial_dev, dw_dev, db_dev, B, H, W, st);                \
+    case PMX_OBS_BF16: return launch_proj_bwd<NT, __hip_bfloat16>(obs_dev, dtokens_dev, partial_dev, dw_dev, db_dev, B, H, W, st);      \
+    case PMX_OBS_U8: return launch_proj_bwd<NT, uint8_t>(obs_dev, dtokens_dev, partial_dev, dw_dev, db_dev, B, H, W, st);               \
+    default: return PMX_ERR_INVALID;                                                                                                \
+    }
+    if (nt == 10) { PMX_PB(10) }
+    if (nt == 28) { PMX_PB(28) }
+    PMX_PB(11)
+#undef PMX_PB
+}
+
 #ifdef PMX_ACTOR_TIMING
 extern "C" int pmx_actor_ticks_read(unsigned long long *out, int reset)
 {

@@ -432,14 +432,16 @@ __global__ __launch_bounds__(256) void pmx_sum_rows_kernel(float *__restrict__ b
 // ---------------------------------------------------------------------------------------------------------------
 // float32 parameters -> operand fragments.  hidden order phi, output / input order psi (file header).
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pmx_ffn_pack_kernel(const float *__restrict__ w1, const float *__restrict__ b1, const float *__restrict__ w2,
-                                                          const float *__restrict__ b2, const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                          char *__restrict__ pack)
+// (bx, nbx: the block's index and the number of blocks that share the job -- the stand-alone kernel passes blockIdx.x / gridDim.x, the
+// one-launch encoder pack its own split)
+__device__ __forceinline__ void ffn_pack_body(const float *__restrict__ w1, const float *__restrict__ b1, const float *__restrict__ w2,
+                                              const float *__restrict__ b2, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                              char *__restrict__ pack, int bx, int nbx)
 {
     // w1 [128][32] (linear1.weight), w2 [32][128] (linear2.weight)
     short *a1 = reinterpret_cast<short *>(pack + P_A1), *a2 = reinterpret_cast<short *>(pack + P_A2);
     short *a3 = reinterpret_cast<short *>(pack + P_A3), *a4 = reinterpret_cast<short *>(pack + P_A4);
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < 8 * FRAG; i += gridDim.x * 256) {
+    for (int i = bx * 256 + threadIdx.x; i < 8 * FRAG; i += nbx * 256) {
         const int j = i & 7, lane = (i >> 3) & 63, f = i >> 9;          // fragment f, lane, element j
         const int row = lane & 15, g = lane >> 4;
         const int psi_row = 8 * (row >> 2) + (row & 3);                 // + 4 * half
@@ -453,11 +455,18 @@ __global__ __launch_bounds__(256) void pmx_ffn_pack_kernel(const float *__restri
         // A4[mo][s]: W1[hidden phi(s, g, j)][in psi(mo, row)]  (dX = W1^T dH)
         a4[i] = (short)(pack2(w1[phi(f & 3) * 32 + psi_row + 4 * (f >> 2)], 0.f) & 0xFFFF);
     }
-    if (blockIdx.x == 0) {
+    if (bx == 0) {
         float *pb = reinterpret_cast<float *>(pack + P_B1);
         for (int i = threadIdx.x; i < 128; i += 256) pb[i] = b1[i];
         if (threadIdx.x < 32) pb[128 + threadIdx.x] = b2[threadIdx.x], pb[160 + threadIdx.x] = gamma[threadIdx.x], pb[192 + threadIdx.x] = beta[threadIdx.x];
     }
+}
+
+__global__ __launch_bounds__(256) void pmx_ffn_pack_kernel(const float *__restrict__ w1, const float *__restrict__ b1, const float *__restrict__ w2,
+                                                          const float *__restrict__ b2, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                          char *__restrict__ pack)
+{
+    ffn_pack_body(w1, b1, w2, b2, gamma, beta, pack, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -706,12 +715,12 @@ __global__ __launch_bounds__(256, 2) void pmx_tok_bwd_kernel(const uint4 *__rest
 }
 
 template <int NP>
-__global__ __launch_bounds__(256) void pmx_tok_pack_kernel(const float *__restrict__ w, const float *__restrict__ b, const float *__restrict__ gamma,
-                                                          const float *__restrict__ beta, char *__restrict__ pack)
+__device__ __forceinline__ void tok_pack_body(const float *__restrict__ w, const float *__restrict__ b, const float *__restrict__ gamma,
+                                              const float *__restrict__ beta, char *__restrict__ pack, int bx, int nbx)
 {
     // w [32 NP][32] (nn.Linear weight)
     short *af = reinterpret_cast<short *>(pack + TokPack<NP>::A_FWD), *ab = reinterpret_cast<short *>(pack + TokPack<NP>::A_BWD);
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * NP * FRAG; i += gridDim.x * 256) {
+    for (int i = bx * 256 + threadIdx.x; i < 2 * NP * FRAG; i += nbx * 256) {
         const int j = i & 7, lane = (i >> 3) & 63, f = i >> 9;
         const int row = lane & 15, g = lane >> 4;
         const int psi_row = 8 * (row >> 2) + (row & 3);
@@ -720,7 +729,7 @@ __global__ __launch_bounds__(256) void pmx_tok_pack_kernel(const float *__restri
         // backward fragment f = mo * NP + q: W[out 32 q + 8 g + j][in psi(mo, row)]
         ab[i] = (short)(pack2(w[(32 * (f % NP) + 8 * g + j) * 32 + psi_row + 4 * (f / NP)], 0.f) & 0xFFFF);
     }
-    if (blockIdx.x == 0) {
+    if (bx == 0) {
         float *pf = reinterpret_cast<float *>(pack + TokPack<NP>::FLT);
         for (int i = threadIdx.x; i < 32 * NP; i += 256) pf[i] = b[i];
         if (threadIdx.x < 32) {
@@ -728,6 +737,27 @@ __global__ __launch_bounds__(256) void pmx_tok_pack_kernel(const float *__restri
             pf[32 * NP + 32 + threadIdx.x] = beta ? beta[threadIdx.x] : 0.f;
         }
     }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void pmx_tok_pack_kernel(const float *__restrict__ w, const float *__restrict__ b, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, char *__restrict__ pack)
+{
+    tok_pack_body<NP>(w, b, gamma, beta, pack, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// every pack of up to four encoder layers in ONE launch: blockIdx.y = 3 * layer + (0 in-projection | 1 out-projection + norm1 |
+// 2 feed-forward + norm2), 8 blocks per job (six small pack launches sat in front of the kernels of the launch-bound 512-sample step)
+struct EncoderPackArgs {
+    pmx_encoder_layer_params l[4];
+};
+__global__ __launch_bounds__(256) void pmx_encoder_pack_kernel(EncoderPackArgs a)
+{
+    const pmx_encoder_layer_params &L = a.l[blockIdx.y / 3];
+    const int which = blockIdx.y % 3, bx = (int)blockIdx.x, nbx = (int)gridDim.x;
+    if (which == 0) tok_pack_body<3>(L.in_proj_w, L.in_proj_b, nullptr, nullptr, reinterpret_cast<char *>(L.pack_in), bx, nbx);
+    else if (which == 1) tok_pack_body<1>(L.out_proj_w, L.out_proj_b, L.norm1_w, L.norm1_b, reinterpret_cast<char *>(L.pack_out), bx, nbx);
+    else ffn_pack_body(L.lin1_w, L.lin1_b, L.lin2_w, L.lin2_b, L.norm2_w, L.norm2_b, reinterpret_cast<char *>(L.pack_ffn), bx, nbx);
 }
 
 int cu_count()
@@ -738,6 +768,21 @@ int cu_count()
 }
 
 }   // namespace
+
+extern "C" int pmx_encoder_pack(int32_t n_layers, const pmx_encoder_layer_params *layers, void *stream)
+{
+    if (n_layers < 1 || n_layers > 4 || !layers) return PMX_ERR_INVALID;
+    EncoderPackArgs a;
+    for (int i = 0; i < n_layers; ++i) {
+        a.l[i] = layers[i];
+        const pmx_encoder_layer_params &L = a.l[i];
+        if (!L.in_proj_w || !L.in_proj_b || !L.out_proj_w || !L.out_proj_b || !L.norm1_w || !L.norm1_b || !L.lin1_w || !L.lin1_b || !L.lin2_w ||
+            !L.lin2_b || !L.norm2_w || !L.norm2_b || !L.pack_in || !L.pack_out || !L.pack_ffn)
+            return PMX_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(pmx_encoder_pack_kernel, dim3(8, 3 * n_layers), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
 
 extern "C" int pmx_ffn_pack(const float *w1, const float *b1, const float *w2, const float *b2, const float *gamma, const float *beta,
                             void *pack_dev, void *stream)
@@ -756,6 +801,22 @@ extern "C" int pmx_ffn_forward(const void *x_dev, const void *pack_dev, void *y_
     const int64_t want = (tiles + 3) / 4, cap = (int64_t)cu_count() * 2;
     hipLaunchKernelGGL(pmx_ffn_fwd_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        (const uint4 *)x_dev, (const char *)pack_dev, (uint4 *)y_dev, (long)tokens, eps);
+    return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
+}
+
+// Deferred row sums: with pmx_defer_row_sums(1) the backward entry points of this file and of pmx_heads.hip leave their partial rows
+// unsummed and report how many there are (pmx_last_partial_rows); the caller adds them with pmx_sum_partial_rows on a stream of its
+// choice -- a side stream, so that the second stage of one gradient reduction runs beside the next backward kernel instead of in
+// front of it (six small launches on the critical path of the launch-bound 512-sample step).  Per host thread.
+thread_local int pmx_defer_sums_flag = 0;
+thread_local int pmx_last_rows_value = 0;
+extern "C" int pmx_defer_row_sums(int32_t on) { pmx_defer_sums_flag = on ? 1 : 0; return PMX_OK; }
+extern "C" int pmx_last_partial_rows(void) { return pmx_last_rows_value; }
+extern "C" int pmx_sum_partial_rows(float *buf_dev, int32_t n_rows, int32_t floats, void *stream)
+{
+    if (!buf_dev || n_rows < 0 || floats < 1) return PMX_ERR_INVALID;
+    if (n_rows == 0) return PMX_OK;
+    hipLaunchKernelGGL(pmx_sum_rows_kernel, dim3((floats + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), buf_dev, (int)n_rows, (int)floats);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
 
@@ -781,7 +842,9 @@ extern "C" int pmx_ffn_backward(const void *x_dev, const void *dy_dev, const voi
     const unsigned blocks = (unsigned)(want < cap ? want : cap);
     hipLaunchKernelGGL(pmx_ffn_bwd_kernel, dim3(blocks), dim3(256), lds, st, (const uint4 *)x_dev, (const uint4 *)dy_dev,
                        (const char *)pack_dev, (uint4 *)dx_dev, grad_dev, (long)tokens, eps);
-    hipLaunchKernelGGL(pmx_sum_rows_kernel, dim3((G_FLOATS + 31) / 32), dim3(256), 0, st, grad_dev, (int)blocks, (int)G_FLOATS);
+    pmx_last_rows_value = (int)blocks;
+    if (!pmx_defer_sums_flag)
+        hipLaunchKernelGGL(pmx_sum_rows_kernel, dim3((G_FLOATS + 31) / 32), dim3(256), 0, st, grad_dev, (int)blocks, (int)G_FLOATS);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
 
@@ -810,7 +873,9 @@ int tok_backward(const void *a, const void *x, const void *dy, const void *pack,
     const unsigned blocks = (unsigned)(want < cap ? want : cap);
     hipLaunchKernelGGL((pmx_tok_bwd_kernel<NP, LN>), dim3(blocks), dim3(256), lds, st, (const uint4 *)a, (const uint4 *)x,
                        (const uint4 *)dy, (const char *)pack, (uint4 *)da, (uint4 *)dx, grad, (long)tokens, eps);
-    hipLaunchKernelGGL(pmx_sum_rows_kernel, dim3((TokPack<NP>::G_FLOATS + 31) / 32), dim3(256), 0, st, grad, (int)blocks, (int)TokPack<NP>::G_FLOATS);
+    pmx_last_rows_value = (int)blocks;
+    if (!pmx_defer_sums_flag)
+        hipLaunchKernelGGL(pmx_sum_rows_kernel, dim3((TokPack<NP>::G_FLOATS + 31) / 32), dim3(256), 0, st, grad, (int)blocks, (int)TokPack<NP>::G_FLOATS);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
 }   // namespace

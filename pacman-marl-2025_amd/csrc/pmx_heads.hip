@@ -17,6 +17,9 @@
 
 #include "../../include/pmx.h"
 
+extern thread_local int pmx_defer_sums_flag;       // pmx_critic.hip: deferred row sums (pmx_defer_row_sums)
+extern thread_local int pmx_last_rows_value;
+
 namespace {
 
 constexpr int HID = 512, PER_LANE = 8, NACT = 5, DM = 32;
@@ -444,7 +447,9 @@ extern "C" int pmx_actor_tail_backward(const void *h_dev, int32_t h_bf16, const 
     const int blocks = heads_blocks(B, PMX_HEADS_PARTIAL_ROWS);
     if (h_bf16) hipLaunchKernelGGL(pmx_actor_tail_bwd_kernel<__hip_bfloat16>, dim3(blocks), dim3(256), 0, st, (const __hip_bfloat16 *)h_dev, stats_dev, dlogits_dev, ln_w, ln_b, w2, (__hip_bfloat16 *)dh_dev, grad_dev, (int)B);
     else hipLaunchKernelGGL(pmx_actor_tail_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float *)h_dev, stats_dev, dlogits_dev, ln_w, ln_b, w2, (float *)dh_dev, grad_dev, (int)B);
-    hipLaunchKernelGGL(pmx_heads_sum_rows_kernel, dim3((AT_FLOATS + 31) / 32), dim3(256), 0, st, grad_dev, blocks, (int)AT_FLOATS);
+    pmx_last_rows_value = blocks;
+    if (!pmx_defer_sums_flag)
+        hipLaunchKernelGGL(pmx_heads_sum_rows_kernel, dim3((AT_FLOATS + 31) / 32), dim3(256), 0, st, grad_dev, blocks, (int)AT_FLOATS);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
 
@@ -498,7 +503,8 @@ extern "C" int pmx_critic_tail_backward(const float *pooled_dev, const float *dv
     const int n_chunks = (int)((B + chunk - 1) / chunk);
     hipLaunchKernelGGL(pmx_critic_tail_wgrad_kernel, dim3(HID / 8, n_chunks), dim3(256), 0, st, (const __hip_bfloat16 *)dh, (const __hip_bfloat16 *)g,
                        pooled_dev, dvalue_dev, grad_dev, (int)B, (int)chunk, n_chunks == 1 ? 1 : 0);
-    if (n_chunks > 1)
+    pmx_last_rows_value = n_chunks > 1 ? n_chunks : 0;                 // (one chunk: the sums went straight to row 0)
+    if (n_chunks > 1 && !pmx_defer_sums_flag)
         hipLaunchKernelGGL(pmx_heads_sum_rows_kernel, dim3((CT_FLOATS + 31) / 32), dim3(256), 0, st, grad_dev, n_chunks, (int)CT_FLOATS);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }

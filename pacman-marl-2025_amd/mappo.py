@@ -34,6 +34,54 @@ def layer_norm_small(x, ln):
     return ((xf - mean) * torch.rsqrt(var + ln.eps) * ln.weight + ln.bias).to(x.dtype)
 
 
+_SUM_STREAMS, _SUMS_PENDING = {}, set()
+_DEFER_ROW_SUMS = [False]  # True only while PPOLearner._backward_group runs autograd (it joins the side stream before it reads the
+                           # gradients); any other caller of these autograd functions gets the summed row on its own stream
+
+
+class _row_sums_deferred:
+    """Context for ONE backward call of the pmx_ffn / tok96 / tok32ln / *_tail families: the library skips the small row-sum kernel
+    that ends it, and on exit the rows are added on a per-device side stream instead -- beside the next backward kernel of the
+    chain rather than in front of it.  The consumer of the summed row (the gradient gather of PPOLearner._backward_group, or
+    join_row_sums()) waits for that stream."""
+
+    def __init__(self, lib, grad, floats):
+        self.lib, self.grad, self.floats = lib, grad, floats
+        self.on = _DEFER_ROW_SUMS[0] and grad.is_cuda
+
+    def __enter__(self):
+        if self.on:
+            self.lib.pmx_defer_row_sums(1)
+        return self
+
+    def __exit__(self, *exc):
+        if not self.on:
+            return False
+        self.lib.pmx_defer_row_sums(0)
+        n = self.lib.pmx_last_partial_rows()
+        if exc[0] is None and n > 0:
+            import ctypes as C
+            from . import _lib
+            dev = self.grad.device
+            key = dev.index if dev.index is not None else torch.cuda.current_device()
+            ss = _SUM_STREAMS.get(key)
+            if ss is None:
+                ss = _SUM_STREAMS[key] = torch.cuda.Stream(device=dev)
+            ss.wait_stream(torch.cuda.current_stream(dev))
+            _lib.check(self.lib.pmx_sum_partial_rows(self.grad.data_ptr(), n, self.floats, C.c_void_p(ss.cuda_stream)), "pmx_sum_partial_rows")
+            self.grad.record_stream(ss)
+            _SUMS_PENDING.add(key)
+        return False
+
+
+def join_row_sums(dev):
+    """Makes the current stream wait for the row sums issued on the side stream (no-op when none are pending)."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key in _SUMS_PENDING:
+        torch.cuda.current_stream(dev).wait_stream(_SUM_STREAMS[key])
+        _SUMS_PENDING.discard(key)
+
+
 class _LN32Residual(torch.autograd.Function):
     """LayerNorm(x + a) over a 32-wide feature dimension through the fused HIP kernels pmx_ln32_forward/backward."""
 
@@ -85,16 +133,15 @@ class _FFNLayerNorm(torch.autograd.Function):
     (csrc/pmx_critic.hip): one kernel each way, the 128-wide hidden activations never reach memory, backward recomputes."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps):
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps, pack=None):
         import ctypes as C
         from . import _lib
         lib = _lib.load()
         x = x.contiguous()
         dev = x.device
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        ps = [t.detach().float().contiguous() for t in (w1, b1, w2, b2, gamma, beta)]
-        pack = torch.empty(_lib.FFN_PACK_BYTES, dtype=torch.uint8, device=dev)
-        _lib.check(lib.pmx_ffn_pack(*[t.data_ptr() for t in ps], pack.data_ptr(), st), "pmx_ffn_pack")
+        if pack is None:
+            pack = pack_ffn(w1, b1, w2, b2, gamma, beta)
         y = torch.empty_like(x)
         _lib.check(lib.pmx_ffn_forward(x.data_ptr(), pack.data_ptr(), y.data_ptr(), x.numel() // 32, float(eps), st), "pmx_ffn_forward")
         ctx.save_for_backward(x, pack)
@@ -113,27 +160,89 @@ class _FFNLayerNorm(torch.autograd.Function):
         dy = dy.to(torch.bfloat16).contiguous()
         dx = torch.empty_like(x)
         grad = torch.empty((1 + _lib.GRAD_PARTIAL_ROWS) * _lib.FFN_GRAD_FLOATS, dtype=torch.float32, device=dev)   # row 0 = the result
-        _lib.check(lib.pmx_ffn_backward(x.data_ptr(), dy.data_ptr(), pack.data_ptr(), dx.data_ptr(), grad.data_ptr(), x.numel() // 32,
-                                        ctx.eps, st), "pmx_ffn_backward")
+        with _row_sums_deferred(lib, grad, _lib.FFN_GRAD_FLOATS):
+            _lib.check(lib.pmx_ffn_backward(x.data_ptr(), dy.data_ptr(), pack.data_ptr(), dx.data_ptr(), grad.data_ptr(), x.numel() // 32,
+                                            ctx.eps, st), "pmx_ffn_backward")
         dw2, dw1 = grad[:4096].view(32, 128), grad[4096:8192].view(128, 32)
         db1, db2, dg, dbeta = grad[8192:8320], grad[8320:8352], grad[8352:8384], grad[8384:8416]
         outs = (dw1, db1, dw2, db2, dg, dbeta)
-        return (dx,) + tuple(o.to(dt) for o, dt in zip(outs, ctx.dtypes)) + (None,)
+        return (dx,) + tuple(o.to(dt) for o, dt in zip(outs, ctx.dtypes)) + (None, None)
+
+
+def pack_ffn(w1, b1, w2, b2, gamma, beta):
+    """The feed-forward half's parameters in the kernels' operand layout (pmx_ffn_pack), on the current stream."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    ps = [t.detach().float().contiguous() for t in (w1, b1, w2, b2, gamma, beta)]
+    pack = torch.empty(_lib.FFN_PACK_BYTES, dtype=torch.uint8, device=ps[0].device)
+    st = C.c_void_p(torch.cuda.current_stream(ps[0].device).cuda_stream)
+    _lib.check(lib.pmx_ffn_pack(*[t.data_ptr() for t in ps], pack.data_ptr(), st), "pmx_ffn_pack")
+    return pack
+
+
+def pack_in_proj(w, b):
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    wf, bf = w.detach().float().contiguous(), b.detach().float().contiguous()
+    pack = torch.empty(_lib.TOK96_PACK_BYTES, dtype=torch.uint8, device=wf.device)
+    st = C.c_void_p(torch.cuda.current_stream(wf.device).cuda_stream)
+    _lib.check(lib.pmx_tok96_pack(wf.data_ptr(), bf.data_ptr(), pack.data_ptr(), st), "pmx_tok96_pack")
+    return pack
+
+
+def pack_out_proj(w, b, gamma, beta):
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    ps = [t.detach().float().contiguous() for t in (w, b, gamma, beta)]
+    pack = torch.empty(_lib.TOK32_PACK_BYTES, dtype=torch.uint8, device=ps[0].device)
+    st = C.c_void_p(torch.cuda.current_stream(ps[0].device).cuda_stream)
+    _lib.check(lib.pmx_tok32ln_pack(*[t.data_ptr() for t in ps], pack.data_ptr(), st), "pmx_tok32ln_pack")
+    return pack
+
+
+def encoder_packs(layers):
+    """The three parameter packs (in-projection, out-projection + norm1, feed-forward + norm2) of every given CriticEncoderLayer in
+    ONE launch (pmx_encoder_pack) on the current stream -> [(pack_in, pack_out, pack_ffn), ...]."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    n = len(layers)
+    arr = (_lib.EncoderLayerParams * n)()
+    keep, out = [], []
+    dev = layers[0].linear1.weight.device
+    for i, l in enumerate(layers):
+        mha = l.self_attn
+        ps = [t.detach().float().contiguous() for t in (mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias,
+                                                        l.norm1.weight, l.norm1.bias, l.linear1.weight, l.linear1.bias, l.linear2.weight,
+                                                        l.linear2.bias, l.norm2.weight, l.norm2.bias)]
+        keep.append(ps)
+        packs = (torch.empty(_lib.TOK96_PACK_BYTES, dtype=torch.uint8, device=dev), torch.empty(_lib.TOK32_PACK_BYTES, dtype=torch.uint8, device=dev),
+                 torch.empty(_lib.FFN_PACK_BYTES, dtype=torch.uint8, device=dev))
+        for name, t in zip(("in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "norm1_w", "norm1_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b",
+                            "norm2_w", "norm2_b"), ps):
+            setattr(arr[i], name, t.data_ptr())
+        arr[i].pack_in, arr[i].pack_out, arr[i].pack_ffn = (p.data_ptr() for p in packs)
+        out.append(packs)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(lib.pmx_encoder_pack(n, arr, st), "pmx_encoder_pack")
+    return out
 
 
 class _InProj96(torch.autograd.Function):
     """qkv = in_proj_weight a + in_proj_bias on [..., 32] bfloat16 tokens (pmx_tok96_forward / _backward)."""
 
     @staticmethod
-    def forward(ctx, a, w, b):
+    def forward(ctx, a, w, b, pack=None):
         import ctypes as C
         from . import _lib
         lib = _lib.load()
         a = a.contiguous()
         st = C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
-        wf, bf = w.detach().float().contiguous(), b.detach().float().contiguous()
-        pack = torch.empty(_lib.TOK96_PACK_BYTES, dtype=torch.uint8, device=a.device)
-        _lib.check(lib.pmx_tok96_pack(wf.data_ptr(), bf.data_ptr(), pack.data_ptr(), st), "pmx_tok96_pack")
+        if pack is None:
+            pack = pack_in_proj(w, b)
         y = torch.empty(a.shape[:-1] + (96,), dtype=torch.bfloat16, device=a.device)
         _lib.check(lib.pmx_tok96_forward(a.data_ptr(), pack.data_ptr(), y.data_ptr(), a.numel() // 32, st), "pmx_tok96_forward")
         ctx.save_for_backward(a, pack)
@@ -150,24 +259,24 @@ class _InProj96(torch.autograd.Function):
         dy = dy.to(torch.bfloat16).contiguous()
         da = torch.empty_like(a)
         grad = torch.empty((1 + _lib.GRAD_PARTIAL_ROWS) * _lib.TOK96_GRAD_FLOATS, dtype=torch.float32, device=a.device)
-        _lib.check(lib.pmx_tok96_backward(a.data_ptr(), dy.data_ptr(), pack.data_ptr(), da.data_ptr(), grad.data_ptr(), a.numel() // 32, st),
-                   "pmx_tok96_backward")
-        return da, grad[:3072].view(96, 32).to(ctx.dtypes[0]), grad[3072:3168].to(ctx.dtypes[1])
+        with _row_sums_deferred(lib, grad, _lib.TOK96_GRAD_FLOATS):
+            _lib.check(lib.pmx_tok96_backward(a.data_ptr(), dy.data_ptr(), pack.data_ptr(), da.data_ptr(), grad.data_ptr(), a.numel() // 32, st),
+                       "pmx_tok96_backward")
+        return da, grad[:3072].view(96, 32).to(ctx.dtypes[0]), grad[3072:3168].to(ctx.dtypes[1]), None
 
 
 class _OutProjAddLN(torch.autograd.Function):
     """LayerNorm(x + out_proj.weight a + out_proj.bias) on [..., 32] bfloat16 tokens (pmx_tok32ln_forward / _backward)."""
 
     @staticmethod
-    def forward(ctx, x, a, w, b, gamma, beta, eps):
+    def forward(ctx, x, a, w, b, gamma, beta, eps, pack=None):
         import ctypes as C
         from . import _lib
         lib = _lib.load()
         x, a = x.contiguous(), a.contiguous()
         st = C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
-        ps = [t.detach().float().contiguous() for t in (w, b, gamma, beta)]
-        pack = torch.empty(_lib.TOK32_PACK_BYTES, dtype=torch.uint8, device=a.device)
-        _lib.check(lib.pmx_tok32ln_pack(*[t.data_ptr() for t in ps], pack.data_ptr(), st), "pmx_tok32ln_pack")
+        if pack is None:
+            pack = pack_out_proj(w, b, gamma, beta)
         y = torch.empty_like(x)
         _lib.check(lib.pmx_tok32ln_forward(x.data_ptr(), a.data_ptr(), pack.data_ptr(), y.data_ptr(), x.numel() // 32, float(eps), st),
                    "pmx_tok32ln_forward")
@@ -186,10 +295,11 @@ class _OutProjAddLN(torch.autograd.Function):
         dy = dy.to(torch.bfloat16).contiguous()
         dx, da = torch.empty_like(x), torch.empty_like(a)
         grad = torch.empty((1 + _lib.GRAD_PARTIAL_ROWS) * _lib.TOK32_GRAD_FLOATS, dtype=torch.float32, device=a.device)
-        _lib.check(lib.pmx_tok32ln_backward(x.data_ptr(), a.data_ptr(), dy.data_ptr(), pack.data_ptr(), dx.data_ptr(), da.data_ptr(),
-                                            grad.data_ptr(), x.numel() // 32, ctx.eps, st), "pmx_tok32ln_backward")
+        with _row_sums_deferred(lib, grad, _lib.TOK32_GRAD_FLOATS):
+            _lib.check(lib.pmx_tok32ln_backward(x.data_ptr(), a.data_ptr(), dy.data_ptr(), pack.data_ptr(), dx.data_ptr(), da.data_ptr(),
+                                                grad.data_ptr(), x.numel() // 32, ctx.eps, st), "pmx_tok32ln_backward")
         outs = (grad[:1024].view(32, 32), grad[1024:1056], grad[1056:1088], grad[1088:1120])
-        return (dx, da) + tuple(o.to(dt) for o, dt in zip(outs, ctx.dtypes)) + (None,)
+        return (dx, da) + tuple(o.to(dt) for o, dt in zip(outs, ctx.dtypes)) + (None, None)
 
 
 def _fused_tokens_ok(x, *weights):
@@ -197,24 +307,24 @@ def _fused_tokens_ok(x, *weights):
             and all(w.dtype == torch.float32 for w in weights))
 
 
-def in_proj96(x, mha):
+def in_proj96(x, mha, pack=None):
     if _fused_tokens_ok(x, mha.in_proj_weight) and tuple(mha.in_proj_weight.shape) == (96, 32):
-        return _InProj96.apply(x, mha.in_proj_weight, mha.in_proj_bias)
+        return _InProj96.apply(x, mha.in_proj_weight, mha.in_proj_bias, pack)
     return token_linear(x, mha.in_proj_weight, mha.in_proj_bias)
 
 
-def out_proj_add_layer_norm(x, a, proj, ln):
+def out_proj_add_layer_norm(x, a, proj, ln, pack=None):
     if _fused_tokens_ok(x, proj.weight) and a.dtype == torch.bfloat16 and tuple(proj.weight.shape) == (32, 32):
-        return _OutProjAddLN.apply(x, a, proj.weight, proj.bias, ln.weight, ln.bias, ln.eps)
+        return _OutProjAddLN.apply(x, a, proj.weight, proj.bias, ln.weight, ln.bias, ln.eps, pack)
     return add_layer_norm_small(x, token_linear(a, proj.weight, proj.bias), ln)
 
 
-def ffn_layer_norm(x, lin1, lin2, ln):
+def ffn_layer_norm(x, lin1, lin2, ln, pack=None):
     """The feed-forward half of the post-LN encoder layer: the fused HIP kernels for bf16 tokens of width 32 with a 128-wide
     hidden layer on the GPU, the separate ops otherwise."""
     if (x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] == 32 and tuple(lin1.weight.shape) == (128, 32)
             and tuple(lin2.weight.shape) == (32, 128) and lin1.weight.dtype == torch.float32 and MAPPOAgent.fused_ffn):
-        return _FFNLayerNorm.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias, ln.weight, ln.bias, ln.eps)
+        return _FFNLayerNorm.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias, ln.weight, ln.bias, ln.eps, pack)
     f = token_linear(F.relu(token_linear(x, lin1.weight, lin1.bias)), lin2.weight, lin2.bias)
     return add_layer_norm_small(x, f, ln)
 
@@ -264,6 +374,58 @@ def attention8(qkv, batch_major=False):
     return _Attention8.apply(qkv, batch_major)
 
 
+def pack_projector(w, b):
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    wf, bf = w.detach().float().contiguous(), b.detach().float().contiguous()
+    pack = torch.empty(_lib.PROJ_PACK_BYTES, dtype=torch.uint8, device=wf.device)
+    st = C.c_void_p(torch.cuda.current_stream(wf.device).cuda_stream)
+    _lib.check(lib.pmx_proj_pack(wf.data_ptr(), bf.data_ptr(), pack.data_ptr(), st), "pmx_proj_pack")
+    return pack
+
+
+class _Projector(torch.autograd.Function):
+    """tokens [B, H*W, 32] bf16 = conv3x3(8 -> 32)(obs) + bias + positional table, batch-major, through pmx_proj_forward / _backward
+    (csrc/pmx_actor.hip): the observation planes are read as they are (bytes), no cast, no layout copy, no library convolution."""
+
+    @staticmethod
+    def forward(ctx, obs, w, b, pe, pack=None):
+        import ctypes as C
+        from . import _lib
+        from .actor_tower import _OBS_CODE
+        lib = _lib.load()
+        obs = obs.contiguous()
+        B, _, H, W = obs.shape
+        if pack is None:
+            pack = pack_projector(w, b)
+        tok = torch.empty(B, H * W, 32, dtype=torch.bfloat16, device=obs.device)
+        st = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
+        _lib.check(lib.pmx_proj_forward(obs.data_ptr(), _OBS_CODE[obs.dtype], pack.data_ptr(), pe.data_ptr(), tok.data_ptr(), B, H, W, st),
+                   "pmx_proj_forward")
+        ctx.save_for_backward(obs)
+        ctx.dtypes = (w.dtype, b.dtype)
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        import ctypes as C
+        from . import _lib
+        from .actor_tower import _OBS_CODE
+        lib = _lib.load()
+        (obs,) = ctx.saved_tensors
+        B, _, H, W = obs.shape
+        dev = obs.device
+        dtok = dtok.to(torch.bfloat16).contiguous()
+        part = torch.empty(_lib.PROJ_PARTIAL_ROWS * _lib.PROJ_GRAD_ROW_FLOATS, dtype=torch.float32, device=dev)
+        dw = torch.empty(32, 8, 3, 3, dtype=torch.float32, device=dev)
+        db = torch.empty(32, dtype=torch.float32, device=dev)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.pmx_proj_backward(obs.data_ptr(), _OBS_CODE[obs.dtype], dtok.data_ptr(), part.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                         B, H, W, st), "pmx_proj_backward")
+        return None, dw.to(ctx.dtypes[0]), db.to(ctx.dtypes[1]), None, None
+
+
 class _ActorTail(torch.autograd.Function):
     """logits = Linear_5(gelu(LayerNorm_512(h))) through pmx_actor_tail_forward / _backward (csrc/pmx_heads.hip): one launch each
     way (+ a row sum) instead of LayerNorm, GELU, a skinny GEMM, their backward kernels, two bias reductions and the casts."""
@@ -295,8 +457,9 @@ class _ActorTail(torch.autograd.Function):
         G = _lib.ACTOR_TAIL_GRAD_FLOATS
         grad = torch.empty((1 + _lib.HEADS_PARTIAL_ROWS) * G, dtype=torch.float32, device=h.device)
         st = C.c_void_p(torch.cuda.current_stream(h.device).cuda_stream)
-        _lib.check(lib.pmx_actor_tail_backward(h.data_ptr(), 1 if h.dtype == torch.bfloat16 else 0, stats.data_ptr(), dlogits.data_ptr(),
-                                               lnw.data_ptr(), lnb.data_ptr(), w2.data_ptr(), dh.data_ptr(), grad.data_ptr(), B, st), "pmx_actor_tail_backward")
+        with _row_sums_deferred(lib, grad, G):
+            _lib.check(lib.pmx_actor_tail_backward(h.data_ptr(), 1 if h.dtype == torch.bfloat16 else 0, stats.data_ptr(), dlogits.data_ptr(),
+                                                   lnw.data_ptr(), lnb.data_ptr(), w2.data_ptr(), dh.data_ptr(), grad.data_ptr(), B, st), "pmx_actor_tail_backward")
         return dh, grad[2568:3080], grad[3080:3592], grad[:2560].view(5, 512), grad[2560:2565], None
 
 
@@ -332,8 +495,9 @@ class _CriticTail(torch.autograd.Function):
         scratch = torch.empty(2 * B * 512, dtype=torch.bfloat16, device=dev)
         grad = torch.empty((1 + _lib.HEADS_PARTIAL_ROWS) * _lib.CRITIC_TAIL_GRAD_FLOATS, dtype=torch.float32, device=dev)
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(lib.pmx_critic_tail_backward(pooled.data_ptr(), dvalue.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), dtok.data_ptr(),
-                                                scratch.data_ptr(), grad.data_ptr(), B, S, st), "pmx_critic_tail_backward")
+        with _row_sums_deferred(lib, grad, _lib.CRITIC_TAIL_GRAD_FLOATS):
+            _lib.check(lib.pmx_critic_tail_backward(pooled.data_ptr(), dvalue.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), dtok.data_ptr(),
+                                                    scratch.data_ptr(), grad.data_ptr(), B, S, st), "pmx_critic_tail_backward")
         return dtok, grad[:16384].view(512, 32), grad[16384:16896], grad[16896:17408].view(1, 512), grad[17408:17409]
 
 
@@ -420,14 +584,22 @@ class CriticEncoderLayer(nn.TransformerEncoderLayer):
         return (t.is_cuda and t.dtype == torch.bfloat16 and mha.embed_dim == 32 and mha.num_heads == 4
                 and S <= (640 if torch.is_grad_enabled() else 1024))
 
-    def forward_batch_major(self, x):
-        """The same layer on x [B, S, 32] bfloat16 (tokens of a sample contiguous: the memory order of a channels-last
-        convolution output), hand-written kernels only; the caller has checked fused_ok."""
+    def packs(self):
+        """This layer's three parameter packs (in-projection, out-projection + norm1, feed-forward + norm2) on the current stream."""
         mha = self.self_attn
-        qkv = in_proj96(x, mha)
+        return (pack_in_proj(mha.in_proj_weight, mha.in_proj_bias),
+                pack_out_proj(mha.out_proj.weight, mha.out_proj.bias, self.norm1.weight, self.norm1.bias),
+                pack_ffn(self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, self.norm2.weight, self.norm2.bias))
+
+    def forward_batch_major(self, x, packs=None):
+        """The same layer on x [B, S, 32] bfloat16 (tokens of a sample contiguous: the memory order of a channels-last
+        convolution output), hand-written kernels only; the caller has checked fused_ok.  packs: this layer's packs() made ahead."""
+        mha = self.self_attn
+        p_in, p_out, p_ffn = packs if packs is not None else (None, None, None)
+        qkv = in_proj96(x, mha, p_in)
         a = attention8(qkv, True) if torch.is_grad_enabled() else attention8_forward(qkv, batch_major=True)
-        x = out_proj_add_layer_norm(x, a, mha.out_proj, self.norm1)
-        return ffn_layer_norm(x, self.linear1, self.linear2, self.norm2)
+        x = out_proj_add_layer_norm(x, a, mha.out_proj, self.norm1, p_out)
+        return ffn_layer_norm(x, self.linear1, self.linear2, self.norm2, p_ffn)
 
 
 class _GN8Gelu(torch.autograd.Function):
@@ -625,30 +797,66 @@ class MAPPOAgent(nn.Module):
             obs = obs.contiguous(memory_format=torch.channels_last)
         return self.actor_head(self.actor_backbone(obs))
 
+    fused_projector = True  # the critic's projector + positional table as one kernel under bf16 autocast (pmx_proj_forward)
+    prepack = True          # the encoder layers' parameter packs in one launch at the top of value() instead of one in front of each use
+
+    def _pe_table(self, H, W, dev):
+        """The positional table [H*W, 32] float32 on `dev`, built once per board size."""
+        key = (H, W, str(dev))
+        cache = self.__dict__.setdefault("_pe_cache", {})
+        t = cache.get(key)
+        if t is None:
+            t = cache[key] = self.pos_encoder.table(H, W).reshape(H * W, self.d_model).float().contiguous().to(dev)
+        return t
+
+    def _fused_projector_ok(self, merged_obs):
+        conv = self.critic_projector[0]
+        if not (self.fused_projector and merged_obs.dtype in (torch.uint8, torch.bfloat16, torch.float32) and merged_obs.dim() == 4
+                and merged_obs.shape[1] == 8 and conv.weight.dtype == torch.float32 and tuple(conv.weight.shape) == (32, 8, 3, 3)):
+            return False
+        from . import actor_tower
+        return actor_tower.tower_supported(merged_obs.shape[2], merged_obs.shape[3])
+
     def value(self, merged_obs):
         """merged_obs [B,8,H,W] -> [B] (pacman_mappo_resnet.py:160-170)"""
-        if merged_obs.dtype == torch.uint8:
-            merged_obs = merged_obs.to(torch.bfloat16 if (merged_obs.is_cuda and torch.is_autocast_enabled()) else torch.float32)
         layers = self.critic_transformer.layers
-        if (self.batch_major_critic and merged_obs.is_cuda and torch.is_autocast_enabled() and self.fused_ffn
-                and torch.get_autocast_dtype("cuda") == torch.bfloat16 and layers[0].fused_ok(merged_obs.new_empty(0, dtype=torch.bfloat16),
-                                                                                              merged_obs.shape[2] * merged_obs.shape[3])):
+        bm = (self.batch_major_critic and merged_obs.is_cuda and torch.is_autocast_enabled() and self.fused_ffn
+              and torch.get_autocast_dtype("cuda") == torch.bfloat16
+              and layers[0].fused_ok(merged_obs.new_empty(0, dtype=torch.bfloat16), merged_obs.shape[2] * merged_obs.shape[3]))
+        if bm:
             # channels-last end to end: the projector's output [B, H, W, d] IS the token tensor [B, S, d] (no transposing copy
             # on the way in, none for its gradient on the way back) and the encoder layers run batch-major
             B, _, H, W = merged_obs.shape
-            y = self.critic_projector(merged_obs.contiguous(memory_format=torch.channels_last))
-            x = y.permute(0, 2, 3, 1)
-            if not x.is_contiguous():
-                x = x.contiguous()
-            x = (x + self.pos_encoder.table(H, W).to(x.dtype)).reshape(B, H * W, self.d_model)
-            for layer in layers:
-                x = layer.forward_batch_major(x)
+            # every parameter pack of the encoder layers in one launch (they depend on nothing but the weights; six small launches sat in
+            # front of the six kernels that read them).  (Making them on a side stream instead crashes hipStreamEndCapture when that
+            # stream forks from the critic's side stream -- a fork inside a fork -- on ROCm 7.0: tools/r03_iso.sh.)
+            dev = merged_obs.device
+            layer_tuple = tuple(layers)
+            all_f32 = all(p.dtype == torch.float32 for l in layer_tuple for p in l.parameters()) and len(layer_tuple) <= 4
+            fused_proj = self._fused_projector_ok(merged_obs)
+            lpacks = encoder_packs(layer_tuple) if (all_f32 and self.prepack) else None
+            ppack = None
+            if fused_proj:
+                conv = self.critic_projector[0]
+                x = _Projector.apply(merged_obs, conv.weight, conv.bias, self._pe_table(H, W, dev), ppack)
+            else:
+                if merged_obs.dtype == torch.uint8:
+                    merged_obs = merged_obs.to(torch.bfloat16)
+                y = self.critic_projector(merged_obs.contiguous(memory_format=torch.channels_last))
+                x = y.permute(0, 2, 3, 1)
+                if not x.is_contiguous():
+                    x = x.contiguous()
+                x = (x + self.pos_encoder.table(H, W).to(x.dtype)).reshape(B, H * W, self.d_model)
+            for k, layer in enumerate(layers):
+                x = layer.forward_batch_major(x, lpacks[k] if lpacks is not None else None)
             if self.critic_transformer.norm is not None:
                 x = self.critic_transformer.norm(x)
             if self._fused_heads_ok(x):
                 l1, l2 = self.critic_head[0], self.critic_head[2]
                 return _CriticTail.apply(x, l1.weight, l1.bias, l2.weight, l2.bias)
             return self.critic_head(x.mean(dim=1)).squeeze(-1)
+        if merged_obs.dtype == torch.uint8:
+            merged_obs = merged_obs.to(torch.bfloat16 if (merged_obs.is_cuda and torch.is_autocast_enabled()) else torch.float32)
         x = self.pos_encoder(self.critic_projector(merged_obs))
         x = x.flatten(2).permute(2, 0, 1)                                # [H*W, B, d]
         x = self.critic_transformer(x).mean(dim=0)
@@ -783,6 +991,15 @@ def ppo_loss(model, obs, merged, act, old_logp, adv, ret, clip_eps, ent_coef, vf
                   "loss": loss.detach()}
 
 
+import os as _os
+if _os.environ.get("PMX_NO_PREPACK"):
+    MAPPOAgent.prepack = False
+if _os.environ.get("PMX_NO_FUSED_PROJECTOR"):
+    MAPPOAgent.fused_projector = False
+if _os.environ.get("PMX_NO_TWO_STREAMS"):
+    MAPPOAgent.two_streams = False
+
+
 class FlatBucket:
     """All parameters of a module re-homed as views into one flat fp32 buffer; same for the gradients.
     The data-parallel exchange is then ONE all-reduce of `grad` per optimizer step (2.6 M params = 10.5 MB on
@@ -851,6 +1068,10 @@ class PPOLearner:
         fm = SimpleNamespace(evaluate=lambda o, m, a: torch.func.functional_call(self.model, pd, (o, m, a)))
         return ppo_loss(fm, obs, merged, act, old_logp, adv, ret, clip_eps, ent_coef)
 
+    # the second-stage row sums of the gradient reductions on a side stream (mappo._row_sums_deferred).  OFF: measured in the replayed
+    # 512-sample step it LOSES -- 1 380 against 1 995 steps/s; the six fork / join pairs cost the captured graph more than the six
+    # small kernels cost the critic's chain (tools/r03_iso2.sh).  PMX_DEFER_SUMS=1 switches it on for experiments.
+    defer_row_sums = bool(_os.environ.get("PMX_DEFER_SUMS"))
     overlap_allreduce = True   # data parallel: reduce the actor's gradient slice while the critic's backward runs
     graph_overlap_allreduce = False   # ... also in the hipGraph-replayed step (one graph per gradient group); see capture()
 
@@ -882,8 +1103,14 @@ class PPOLearner:
             for i, v in self._shadow_views.items():
                 if lo <= i < hi:
                     targets[i - lo] = v                  # the bfloat16 copy the library op multiplied by
-        grads = torch.autograd.grad(loss, targets, allow_unused=True, retain_graph=retain)
         dev = self.bucket.grad.device
+        prev, _DEFER_ROW_SUMS[0] = _DEFER_ROW_SUMS[0], bool(self.defer_row_sums and dev.type == "cuda")
+        try:
+            grads = torch.autograd.grad(loss, targets, allow_unused=True, retain_graph=retain)
+        finally:
+            _DEFER_ROW_SUMS[0] = prev
+        if dev.type == "cuda":
+            join_row_sums(dev)                               # the deferred second-stage sums of the parameter gradients
         flat = [g.reshape(-1) if g is not None else torch.zeros(p.numel(), dtype=self.bucket.grad.dtype, device=dev)
                 for g, p in zip(grads, params)]
         first = sum(p.numel() for p in self.bucket.params[:lo])
@@ -954,7 +1181,16 @@ class PPOLearner:
     # the WHOLE bucket instead (one cast kernel after the optimizer step); the copy's slices take the parameters' places for the
     # forward pass and receive the gradients, which pmx_flatten_to_f32 widens into the bucket.  Same roundings as autocast's.
     SHADOWED = ("actor_head.0.", "actor_head.3.", "critic_projector.0.", "critic_head.0.", "critic_head.2.")
-    SHADOWED_WITH_FUSED_HEADS = ("actor_head.0.", "critic_projector.0.")    # (the head-tail kernels read the small layers' float32 masters)
+    # (the head-tail kernels and the projector kernel read their layers' float32 masters and round the operands themselves)
+    SMALL_HEAD_LAYERS = ("actor_head.3.", "critic_head.0.", "critic_head.2.")
+
+    def _shadowed_prefixes(self):
+        keep = self.SHADOWED
+        if getattr(self.model, "fused_heads", False):
+            keep = tuple(k for k in keep if k not in self.SMALL_HEAD_LAYERS)
+        if getattr(self.model, "fused_projector", False):
+            keep = tuple(k for k in keep if k != "critic_projector.0.")
+        return keep
     shadow_weights = True
 
     def _shadow_context(self):
@@ -969,7 +1205,7 @@ class PPOLearner:
             names = [n for n, p in self.model.named_parameters() if p.requires_grad]
             self._shadow_slots, off = [], 0
             for i, (n, p) in enumerate(zip(names, self.bucket.params)):
-                if n.startswith(self.SHADOWED_WITH_FUSED_HEADS if getattr(self.model, "fused_heads", False) else self.SHADOWED):
+                if n.startswith(self._shadowed_prefixes()):
                     self._shadow_slots.append((i, n, off, p.numel(), tuple(p.shape)))
                 off += p.numel()
         self._shadow_views, pd = {}, {}

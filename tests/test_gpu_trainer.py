@@ -595,8 +595,9 @@ def test_batch_major_critic_matches_sequence_major_critic():
     m = mappo.MAPPOAgent((8, H, W)).cuda()
     merged = (torch.rand(96, 8, H, W, device="cuda") < 0.2).to(torch.uint8)
     res = {}
-    m.fused_heads = False          # (the head-tail kernels only exist on the batch-major path and have their own tests: here both
-                                   #  layouts run the library head, so that the comparison is about the token layout alone)
+    m.fused_heads = m.fused_projector = False   # (the head-tail and projector kernels only exist on the batch-major path and have their
+                                                #  own tests: here both layouts run the library ops, so that the comparison is about
+                                                #  the token layout alone)
     for bm in (False, True):
         m.batch_major_critic = bm
         m.zero_grad(set_to_none=True)
@@ -851,3 +852,62 @@ def test_fused_heads_are_what_the_model_uses_under_autocast():
     assert res[True][0].dtype == torch.float32
     assert float((res[True][0] - res[False][0]).abs().max()) <= 3e-2 * (1.0 + float(res[False][0].abs().max()))
     assert float((res[True][1] - res[False][1]).abs().max()) <= 3e-2 * (1.0 + float(res[False][1].abs().max()))
+
+
+@pytest.mark.parametrize("layout,B,dtype", [("smallCapture", 300, torch.uint8), ("tinyCapture", 37, torch.bfloat16), ("bloxCapture", 65, torch.uint8),
+                                            ("smallCapture", 3, torch.float32), ("bloxCapture", 700, torch.uint8)])
+def test_fused_projector_matches_torch(layout, B, dtype):
+    """pmx_proj_forward / _backward (critic_projector + positional encoding, pacman_mappo_resnet.py:126-127, :69-95, :164 -> batch-major
+    tokens) against torch in float64 with the kernel's roundings made explicit (bf16 weights, the convolution + bias rounded to bf16,
+    then the bf16 sum with the bf16 table): tokens within one bf16 ulp of the largest, weight / bias gradients within 1e-2."""
+    import pmx
+    from pmx import mappo
+    lay = pmx.get_layout(layout)
+    H, W = lay.height, lay.width
+    torch.manual_seed(B)
+    m = mappo.MAPPOAgent((8, H, W)).cuda()
+    conv = m.critic_projector[0]
+    with torch.no_grad():
+        conv.bias.add_(0.2 * torch.randn(32, device="cuda"))
+    g = torch.Generator(device="cuda").manual_seed(B + 1)
+    obs = (torch.rand(B, 8, H, W, device="cuda", generator=g) < 0.25).float()
+    obs[:, 1] *= torch.randint(1, 6, (B, 1, 1), device="cuda", generator=g).float()
+    pe = m._pe_table(H, W, obs.device)
+    tok = mappo._Projector.apply(obs.to(dtype), conv.weight, conv.bias, pe)
+    assert tok.shape == (B, H * W, 32) and tok.dtype == torch.bfloat16
+    dt = torch.randn(B, H * W, 32, device="cuda", generator=g).to(torch.bfloat16)
+    dw, db = torch.autograd.grad((tok.float() * dt.float()).sum(), [conv.weight, conv.bias])
+    bf = lambda t: t.to(torch.bfloat16).double()
+    w64 = conv.weight.detach().double().requires_grad_(True)
+    b64 = conv.bias.detach().double().requires_grad_(True)
+    wr = w64 + (bf(w64.detach()) - w64.detach())
+    y = torch.nn.functional.conv2d(obs.double(), wr, b64, padding=1)                     # [B, 32, H, W]
+    y = y + (bf(y.detach()) - y.detach())
+    ref = (y.permute(0, 2, 3, 1).reshape(B, H * W, 32) + bf(pe)[None])
+    ref_r = bf(ref.detach())
+    scale = float(ref_r.abs().max())
+    assert float((tok.double() - ref_r).abs().max()) <= scale * 2 ** -7, float((tok.double() - ref_r).abs().max())
+    dw_ref, db_ref = torch.autograd.grad((ref * dt.double()).sum(), [w64, b64])
+    assert float((dw.double() - dw_ref).abs().max()) <= 1e-2 * float(dw_ref.abs().max())
+    assert float((db.double() - db_ref).abs().max()) <= 1e-2 * float(db_ref.abs().max())
+
+
+def test_fused_projector_is_what_the_model_uses_and_agrees_with_the_library_path():
+    from pmx import mappo
+    torch.manual_seed(9)
+    m = mappo.MAPPOAgent((8, 11, 14), 5, 2).cuda()
+    with torch.no_grad():
+        m.critic_head[2].weight.mul_(5.0)
+    obs = (torch.rand(64, 8, 11, 14, device="cuda") < 0.2).to(torch.uint8)
+    res = {}
+    for on in (True, False):
+        m.fused_projector = on
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            v = m.value(obs).float()
+        v.sum().backward()
+        res[on] = (v.detach().clone(), m.critic_projector[0].weight.grad.clone(), m.critic_projector[0].bias.grad.clone())
+    m.fused_projector = True
+    assert float((res[True][0] - res[False][0]).abs().max()) <= 3e-2 * (1.0 + float(res[False][0].abs().max()))
+    for a, b in zip(res[True][1:], res[False][1:]):
+        assert float((a - b).norm() / (b.norm() + 1e-9)) <= 6e-2

@@ -3,7 +3,7 @@ export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
 O=gpurun_out/r3f; mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_gpu_trainer.py -x -q -k "tail or heads" > $O/pytest_heads.log 2>&1; echo "heads rc=$?"; grep -E "^E  |passed|failed" $O/pytest_heads.log | head -12
+timeout -k 10 600 python -m pytest tests/test_gpu_trainer.py -x -q -k "tail or heads or projector" > $O/pytest_heads.log 2>&1; echo "heads rc=$?"; grep -E "^E  |passed|failed" $O/pytest_heads.log | head -12
 timeout -k 10 900 python -m pytest tests -m gpu -q -x > $O/pytest_gpu.log 2>&1; echo "gpu tests rc=$?"; tail -4 $O/pytest_gpu.log
 timeout -k 10 300 python tools/train_bench.py --envs 16384 --horizon 32 --minibatch 16384 --updates 2 > $O/train_small.json 2>/dev/null; tail -c 330 $O/train_small.json; echo
 timeout -k 10 300 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-emit --no-config5 --no-unidirectional > $O/bench_small.json 2> $O/bench_small.err; echo "bench rc=$?"
