@@ -97,6 +97,54 @@ __device__ __forceinline__ float gelu_fast(float z)
     return z * phi_cdf(z, e);
 }
 
+// The same Phi and exp(-z^2 / 2) for a PAIR of values, written so that every step but the reciprocal, the exponential, |z| and the
+// final select is one packed instruction for the pair (v_pk_fma_f32 / v_pk_mul_f32 run at full rate on gfx950): the 1/sqrt 2 and the
+// 0.5 are folded into the constants (a product of constants rounded once, and an exact power of two).
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 unpack2(uint32_t u) { return f32x2{lo_f(u), hi_f(u)}; }
+__device__ __forceinline__ f32x2 phi_cdf2(f32x2 z, f32x2 &e)
+{
+    const f32x2 den = {fmaf(0.3275911f * 0.70710678118654752f, fabsf(z.x), 1.0f), fmaf(0.3275911f * 0.70710678118654752f, fabsf(z.y), 1.0f)};
+    const f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    f32x2 poly = fma2(t, splat2(0.5f * 1.061405429f), splat2(0.5f * -1.453152027f));
+    poly = fma2(poly, t, splat2(0.5f * 1.421413741f));
+    poly = fma2(poly, t, splat2(0.5f * -0.284496736f));
+    poly = fma2(poly, t, splat2(0.5f * 0.254829592f));
+    poly *= t;
+    const f32x2 arg = (z * z) * splat2(-0.5f * 1.4426950408889634f);
+    e = f32x2{__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+    const f32x2 half_tail = poly * e, rest = splat2(1.0f) - half_tail;
+    return f32x2{z.x >= 0.0f ? rest.x : half_tail.x, z.y >= 0.0f ? rest.y : half_tail.y};
+}
+// Pass 1 of the data gradient for the four channels a lane holds of one position: z from the saved convolution output h (GroupNorm,
+// affine, + the skip input x), dz = dY GELU'(z) rounded to bf16 as autograd would round it; the bf16-rounded dz joins the lane's
+// sums for the affine gradients (dgb += dz, dgw += dz xhat).  68 vector instructions (the scalar form, as the compiler packed it,
+// took 95).
+__device__ __forceinline__ uint2 dgelu_quad(uint2 dy, uint2 h2, uint2 x2, float rstd, float nmr, const f32x2 (&gw2)[2], const f32x2 (&gb2)[2],
+                                            f32x2 (&dgw2)[2], f32x2 (&dgb2)[2])
+{
+    f32x2 xh[2], dzf[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const f32x2 hv = unpack2(k ? h2.y : h2.x), xv = unpack2(k ? x2.y : x2.x), d = unpack2(k ? dy.y : dy.x);
+        xh[k] = fma2(hv, splat2(rstd), splat2(nmr));
+        const f32x2 z = xv + fma2(xh[k], gw2[k], gb2[k]);
+        f32x2 e;
+        const f32x2 phi = phi_cdf2(z, e);
+        dzf[k] = d * fma2(z * splat2(0.3989422804014327f), e, phi);
+    }
+    uint2 dzq = {pack2(dzf[0].x, dzf[0].y), pack2(dzf[1].x, dzf[1].y)};
+    asm volatile("" : "+v"(dzq.x), "+v"(dzq.y));
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const f32x2 dzr = unpack2(k ? dzq.y : dzq.x);
+        dgb2[k] += dzr;
+        dgw2[k] = fma2(dzr, xh[k], dgw2[k]);
+    }
+    return dzq;
+}
+
 template <typename T> __device__ __forceinline__ float in_to_f(T v);
 template <> __device__ __forceinline__ float in_to_f<uint8_t>(uint8_t v) { return (float)v; }
 template <> __device__ __forceinline__ float in_to_f<float>(float v) { return v; }
@@ -705,10 +753,14 @@ __global__ __launch_bounds__(256, 1) void pmx_actor_bwd_data_kernel(const char *
             // ---- pass 1: dz = dY GELU'(z), sums for the GroupNorm backward and for the affine gradients -----------------
             float S1[2], S2[2];
             float dgw[2][4], dgb[2][4];
+            f32x2 dgw2[2][2], dgb2[2][2], gw2[2][2], gb2[2][2];       // pairs of channels, for the packed arithmetic of pass 1
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dgw[m][r] = dgb[m][r] = 0.0f;
+                for (int k = 0; k < 2; ++k) {
+                    dgw2[m][k] = dgb2[m][k] = f32x2{0.0f, 0.0f};
+                    gw2[m][k] = f32x2{gw[m][2 * k], gw[m][2 * k + 1]}, gb2[m][k] = f32x2{gb[m][2 * k], gb[m][2 * k + 1]};
+                }
             const uint2 *xsrc = ysave + dump_index((size_t)(l >= 2 ? l - 2 : 0) * B + s, NT, 0, 0, lane);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -720,33 +772,16 @@ __global__ __launch_bounds__(256, 1) void pmx_actor_bwd_data_kernel(const char *
                     }
                 }
 #pragma unroll
-                    for (int m = 0; m < 2; ++m)
-                        {
-                            const uint2 dy = dv[t][m], h2 = hp[t][m], x2 = xg[t][m];
-                            const float hv[4] = {lo_f(h2.x), hi_f(h2.x), lo_f(h2.y), hi_f(h2.y)};
-                            const float xv[4] = {lo_f(x2.x), hi_f(x2.x), lo_f(x2.y), hi_f(x2.y)};
-                            const float d[4] = {lo_f(dy.x), hi_f(dy.x), lo_f(dy.y), hi_f(dy.y)};
-                            float dzf[4], xh[4];
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                xh[r] = fmaf(hv[r], rstd[m], nmr[m]);
-                                const float z = xv[r] + fmaf(xh[r], gw[m][r], gb[m][r]);
-                                float e;
-                                const float phi = phi_cdf(z, e);
-                                dzf[r] = d[r] * fmaf(z * 0.3989422804014327f, e, phi);
-                            }
-                            uint2 dzq = {pack2(dzf[0], dzf[1]), pack2(dzf[2], dzf[3])};
-                            asm volatile("" : "+v"(dzq.x), "+v"(dzq.y));
-                            dv[t][m] = dzq;
-                            const float dzr[4] = {lo_f(dzq.x), hi_f(dzq.x), lo_f(dzq.y), hi_f(dzq.y)};
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                dgb[m][r] += dzr[r];
-                                dgw[m][r] = fmaf(dzr[r], xh[r], dgw[m][r]);
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
+                    for (int m = 0; m < 2; ++m) {
+                        dv[t][m] = dgelu_quad(dv[t][m], hp[t][m], xg[t][m], rstd[m], nmr[m], gw2[m], gb2[m], dgw2[m], dgb2[m]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
             }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    dgw[m][2 * k] = dgw2[m][k].x, dgw[m][2 * k + 1] = dgw2[m][k].y, dgb[m][2 * k] = dgb2[m][k].x, dgb[m][2 * k + 1] = dgb2[m][k].y;
             if (has_res) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
@@ -890,7 +925,7 @@ __global__ __launch_bounds__(256, 1) void pmx_actor_bwd_data_kernel(const char *
 // wave per SIMD either way), the point is the length of a sample's serial chain.
 // ---------------------------------------------------------------------------------------------------------------
 template <int NT, int WS>
-__global__ __launch_bounds__(256, WS == 4 ? 2 : 1) void pmx_actor_bwd_data_split_kernel(const char *__restrict__ pack, const uint2 *__restrict__ dfeat,
+__global__ __launch_bounds__(256, 2) void pmx_actor_bwd_data_split_kernel(const char *__restrict__ pack, const uint2 *__restrict__ dfeat,
                                                                          const uint2 *__restrict__ hsave, const uint2 *__restrict__ ysave,
                                                                          const float *__restrict__ stats, bf16x8 *__restrict__ dasave,
                                                                          uint2 *__restrict__ sktmp, float *__restrict__ accpart, int B,
@@ -995,41 +1030,29 @@ __global__ __launch_bounds__(256, WS == 4 ? 2 : 1) void pmx_actor_bwd_data_split
             // ---- pass 1 on the own tiles ---------------------------------------------------------------------------------
             float S1[2], S2[2];
             float dgw[2][4], dgb[2][4];
+            f32x2 dgw2[2][2], dgb2[2][2], gw2[2][2], gb2[2][2];       // pairs of channels, for the packed arithmetic of pass 1
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dgw[m][r] = dgb[m][r] = 0.0f;
+                for (int k = 0; k < 2; ++k) {
+                    dgw2[m][k] = dgb2[m][k] = f32x2{0.0f, 0.0f};
+                    gw2[m][k] = f32x2{gw[m][2 * k], gw[m][2 * k + 1]}, gb2[m][k] = f32x2{gb[m][2 * k], gb[m][2 * k + 1]};
+                }
 #pragma unroll
             for (int tl = 0; tl < NTW; ++tl) {
                 if (t0 + tl < NT) {
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
-                        const uint2 dy = dv[tl][m], h2 = hp[tl][m], x2 = xg[tl][m];
-                        const float hv[4] = {lo_f(h2.x), hi_f(h2.x), lo_f(h2.y), hi_f(h2.y)};
-                        const float xv[4] = {lo_f(x2.x), hi_f(x2.x), lo_f(x2.y), hi_f(x2.y)};
-                        const float d[4] = {lo_f(dy.x), hi_f(dy.x), lo_f(dy.y), hi_f(dy.y)};
-                        float dzf[4], xh[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            xh[r] = fmaf(hv[r], rstd[m], nmr[m]);
-                            const float z = xv[r] + fmaf(xh[r], gw[m][r], gb[m][r]);
-                            float e;
-                            const float phi = phi_cdf(z, e);
-                            dzf[r] = d[r] * fmaf(z * 0.3989422804014327f, e, phi);
-                        }
-                        uint2 dzq = {pack2(dzf[0], dzf[1]), pack2(dzf[2], dzf[3])};
-                        asm volatile("" : "+v"(dzq.x), "+v"(dzq.y));
-                        dv[tl][m] = dzq;
-                        const float dzr[4] = {lo_f(dzq.x), hi_f(dzq.x), lo_f(dzq.y), hi_f(dzq.y)};
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            dgb[m][r] += dzr[r];
-                            dgw[m][r] = fmaf(dzr[r], xh[r], dgw[m][r]);
-                        }
+                        dv[tl][m] = dgelu_quad(dv[tl][m], hp[tl][m], xg[tl][m], rstd[m], nmr[m], gw2[m], gb2[m], dgw2[m], dgb2[m]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    dgw[m][2 * k] = dgw2[m][k].x, dgw[m][2 * k + 1] = dgw2[m][k].y, dgb[m][2 * k] = dgb2[m][k].x, dgb[m][2 * k + 1] = dgb2[m][k].y;
             if (has_res) {
 #pragma unroll
                 for (int tl = 0; tl < NTW; ++tl)
@@ -1643,12 +1666,16 @@ int launch_bwd(const void *obs, const void *pack, const void *save, const void *
     float *accpart = reinterpret_cast<float *>(sk + (size_t)2048 * dump);       // then the data kernel's per-block partial sums
     int rc;
     int grid_d = grid_for(B, 2);
-    if (large_board(NT) || (B <= split_max_batch() && B <= split_bwd_max_batch())) {
-        // several waves per sample (pmx_actor_bwd_data_split_kernel): every batch of a large board; small batches otherwise.
-        // Measured on smallCapture: 256 samples 56 us, 512 samples 69 us against 118 us for one wave per sample; at 1 024 samples
-        // the split kernels (two waves 160 us, four 135 us) lose to the one-wave kernel (121 us): by then every SIMD has a wave and
-        // the kernel runs at its large-batch rate per sample
-        const int ws = large_board(NT) ? 4 : split_waves(B), spb = 4 / ws;
+    // from this batch on, two waves per sample at two waves per SIMD (PMX_ACTOR_BWD_TWO_WAVE_MIN, read once; 0 = never)
+    static const int64_t two_wave_min = [] { const char *e = getenv("PMX_ACTOR_BWD_TWO_WAVE_MIN"); return e ? (int64_t)atoll(e) : (int64_t)4096; }();
+    const bool two_wave = two_wave_min > 0 && B >= two_wave_min;
+    if (large_board(NT) || two_wave || (B <= split_max_batch() && B <= split_bwd_max_batch())) {
+        // several waves per sample (pmx_actor_bwd_data_split_kernel): every batch of a large board; small batches otherwise
+        // (four waves: 256 samples 56 us, 512 samples 69 us against 118 us for one wave per sample) and LARGE ones (two waves per
+        // sample: the one-wave kernel holds a sample's 44 + 44 registers of gradient and pre-activation and runs one wave per
+        // SIMD; halves of a sample fit two waves per SIMD, and the second wave fills the first one's stalls: backward of 16 384
+        // samples 2.29 -> 2.19 ms, of 8 192 1.21 -> 1.14 ms; between 1 024 and 2 048 samples the one-wave kernel is still ahead)
+        const int ws = large_board(NT) ? 4 : (two_wave ? 2 : split_waves(B)), spb = 4 / ws;
         const size_t lds_s = (size_t)spb * mp * 64 + (size_t)4 * NLAYER * 96 * 4 + (size_t)spb * ws * 8 * 4;
         int64_t g64 = (B + spb - 1) / spb;
         if (g64 > 1024) g64 = 1024;                          // accpart has 1 024 rows; the skip slots (2 048) cover grid * spb
