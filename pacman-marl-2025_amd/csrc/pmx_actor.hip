@@ -76,30 +76,12 @@ __device__ __forceinline__ uint32_t pack2(float a, float b)
 __device__ __forceinline__ float lo_f(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float hi_f(uint32_t u) { return __uint_as_float(u & 0xFFFF0000u); }
 
-// Phi(z) = 0.5 (1 + erf(z / sqrt 2)) by Abramowitz-Stegun 7.1.26 (|error of erf| <= 1.5e-7) and e = exp(-z^2 / 2).
-// GELU(z) = z Phi(z) (nn.GELU() exact form, pacman_mappo_resnet.py:53), GELU'(z) = Phi(z) + z e / sqrt(2 pi).
-__device__ __forceinline__ float phi_cdf(float z, float &e)
-{
-    const float x = fabsf(z) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
-    float poly = fmaf(t, 1.061405429f, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    poly *= t;
-    e = __builtin_amdgcn_exp2f(x * x * -1.4426950408889634f);
-    const float half_tail = 0.5f * poly * e;           // 0.5 erfc(|z| / sqrt 2)
-    return z >= 0.0f ? 1.0f - half_tail : half_tail;
-}
-__device__ __forceinline__ float gelu_fast(float z)
-{
-    float e;
-    return z * phi_cdf(z, e);
-}
-
-// The same Phi and exp(-z^2 / 2) for a PAIR of values, written so that every step but the reciprocal, the exponential, |z| and the
-// final select is one packed instruction for the pair (v_pk_fma_f32 / v_pk_mul_f32 run at full rate on gfx950): the 1/sqrt 2 and the
-// 0.5 are folded into the constants (a product of constants rounded once, and an exact power of two).
+// Phi(z) = 0.5 (1 + erf(z / sqrt 2)) by Abramowitz-Stegun 7.1.26 (|error of erf| <= 1.5e-7) and e = exp(-z^2 / 2), for a PAIR of
+// values.  GELU(z) = z Phi(z) (nn.GELU() exact form, pacman_mappo_resnet.py:53), GELU'(z) = Phi(z) + z e / sqrt(2 pi).
+// Written so that every step but the reciprocal, the exponential, |z| and the final select is one packed instruction for the pair
+// (v_pk_fma_f32 / v_pk_mul_f32 run at full rate on gfx950): t = 1 / (1 + 0.3275911 |z| / sqrt 2), 0.5 erfc(|z| / sqrt 2) =
+// 0.5 t (a1 + t (a2 + ...)) e with the 1 / sqrt 2 and the 0.5 folded into the constants (a product of constants rounded once, and an
+// exact power of two).
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
 __device__ __forceinline__ f32x2 unpack2(uint32_t u) { return f32x2{lo_f(u), hi_f(u)}; }
@@ -116,6 +98,19 @@ __device__ __forceinline__ f32x2 phi_cdf2(f32x2 z, f32x2 &e)
     e = f32x2{__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
     const f32x2 half_tail = poly * e, rest = splat2(1.0f) - half_tail;
     return f32x2{z.x >= 0.0f ? rest.x : half_tail.x, z.y >= 0.0f ? rest.y : half_tail.y};
+}
+// Pass 2 of the forward for the four channels a lane holds of one position: GroupNorm + affine + skip input, GELU, validity mask
+__device__ __forceinline__ uint2 gelu_quad(uint2 h2, uint2 r2, float mean, float rstd, const float (&gw)[4], const float (&gb)[4], float vm)
+{
+    f32x2 v[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const f32x2 hv = unpack2(k ? h2.y : h2.x), rv = unpack2(k ? r2.y : r2.x);
+        const f32x2 z = rv + fma2((hv - splat2(mean)) * splat2(rstd), f32x2{gw[2 * k], gw[2 * k + 1]}, f32x2{gb[2 * k], gb[2 * k + 1]});
+        f32x2 e;
+        v[k] = z * phi_cdf2(z, e) * splat2(vm);
+    }
+    return uint2{pack2(v[0].x, v[0].y), pack2(v[1].x, v[1].y)};
 }
 // Pass 1 of the data gradient for the four channels a lane holds of one position: z from the saved convolution output h (GroupNorm,
 // affine, + the skip input x), dz = dY GELU'(z) rounded to bf16 as autograd would round it; the bf16-rounded dz joins the lane's
@@ -425,16 +420,7 @@ __global__ __launch_bounds__(256, 2) void pmx_actor_fwd_kernel(const IN_T *__res
                 }
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const float hv[4] = {lo_f(hp[t][m].x), hi_f(hp[t][m].x), lo_f(hp[t][m].y), hi_f(hp[t][m].y)};
-                    const uint32_t rx = rres[t][m].x, ry = rres[t][m].y;
-                    const float rv[4] = {lo_f(rx), hi_f(rx), lo_f(ry), hi_f(ry)};
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float z = rv[r] + fmaf((hv[r] - mean[m]) * rstd[m], gw[m][r], gb[m][r]);
-                        v[r] = gelu_fast(z) * vm;
-                    }
-                    const uint2 y2 = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+                    const uint2 y2 = gelu_quad(hp[t][m], rres[t][m], mean[m], rstd[m], gw[m], gb[m], vm);
                     *reinterpret_cast<uint2 *>(wbase + (WPv + 16 * t) * 64 + m * 32) = y2;
                     if (write_y) ydst[(t * 2 + m) * 64] = y2;
                     if (l == NLAYER - 1) {
@@ -624,16 +610,7 @@ __global__ __launch_bounds__(256, 2) void pmx_actor_fwd_split_kernel(const IN_T 
                     const float vm = ((vmk >> tl) & 1) ? 1.0f : 0.0f;
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
-                        const float hv[4] = {lo_f(hp[tl][m].x), hi_f(hp[tl][m].x), lo_f(hp[tl][m].y), hi_f(hp[tl][m].y)};
-                        const uint32_t rx = rres[tl][m].x, ry = rres[tl][m].y;
-                        const float rv[4] = {lo_f(rx), hi_f(rx), lo_f(ry), hi_f(ry)};
-                        float v[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float z = rv[r] + fmaf((hv[r] - mean[m]) * rstd[m], gw[m][r], gb[m][r]);
-                            v[r] = gelu_fast(z) * vm;
-                        }
-                        const uint2 y2 = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+                        const uint2 y2 = gelu_quad(hp[tl][m], rres[tl][m], mean[m], rstd[m], gw[m], gb[m], vm);
                         *reinterpret_cast<uint2 *>(wbase + (WPv + 16 * t) * 64 + m * 32) = y2;
                         if (write_y) ydst[(t * 2 + m) * 64] = y2;
                         if (l == NLAYER - 1) {
