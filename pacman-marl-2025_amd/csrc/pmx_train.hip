@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include <hip/hip_bf16.h>
 
@@ -603,6 +604,7 @@ extern "C" int pmx_gn8_gelu_backward(const void *h, const void *res, const void 
 // ---------------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) short pmx_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float pmx_f32x4;
+typedef __attribute__((ext_vector_type(2))) float pmx_f32x2;
 typedef __attribute__((ext_vector_type(4))) short pmx_bf16x4;
 
 __device__ __forceinline__ short pmx_f2bf(float f)
@@ -720,17 +722,36 @@ __global__ __launch_bounds__(512) void pmx_attn8_fwd_kernel(const __hip_bfloat16
     }
 }
 
+// squared norm of eight bf16 values (one head's row of Q or K)
+__device__ __forceinline__ float sq_norm8(uint4 w)
+{
+    const uint32_t u[4] = {w.x, w.y, w.z, w.w};
+    float n = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float lo = __uint_as_float(u[i] << 16), hi = __uint_as_float(u[i] & 0xFFFF0000u);
+        n = fmaf(lo, lo, n), n = fmaf(hi, hi, n);
+    }
+    return n;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // The forward kernel the product launches (pmx_attn8_fwd_kernel above is kept as the PMX_ATTN_FWD_V1 A/B reference).  The
 // kernel is bound by the vector ALU work of the softmax, so this version removes everything from the inner loop that is not
 // the exponential itself:
-//   * TWO passes over the keys per 16-query tile.  Pass 1 only finds each query's largest raw score (two matrix instructions and
-//     two v_maximum3_f32 per 32 keys; the matrix pipe is otherwise idle), so pass 2 exponentiates against a FIXED reference: no
-//     running maximum, no rescaling of the output tile, no cross-lane traffic inside the loop.  The reference enters pass 2 as the
-//     initial accumulator of the score product (s - m comes out of the matrix instruction), leaving exp2((s - m) c) = one
-//     multiply and one v_exp_f32 per score.
+//   * The exponent's reference is FIXED before the loop over the keys: no running maximum, no rescaling of the output tile, no
+//     cross-lane traffic inside the loop.  It enters as the initial accumulator of the score product (s - m comes out of the
+//     matrix instruction), leaving exp2((s - m) c) = one multiply and one v_exp_f32 per score.  The reference is the
+//     Cauchy-Schwarz bound max_i |q_i| max_j |k_j| of the head (both maxima are found while K and V are staged) whenever that is
+//     harmless: every score lies within [-bound, bound], so with 2 c bound <= 88 the largest probability of a row is at least
+//     2^-88 -- a normal float, and a normal bf16 -- and the common factor cancels in O = P V / l and in the log-sum-exp.  A head
+//     past that limit takes the exact path: a first pass over the keys that only finds each query's largest raw score (two
+//     matrix instructions and four v_maximum3_f32 per 32 keys), ~20 % of the kernel's issue slots when every head needed it.
 //   * The row sum is a matrix product too: V^T is staged with a ninth row of ones, so row 8 of O^T accumulates the sum of the
 //     (bf16-rounded) probabilities that multiply V -- the normaliser is consistent with the numerator and costs no vector add.
+//     The log-sum-exp the backward kernels exponentiate against is taken from the UNROUNDED probabilities instead (four packed
+//     adds per 32 keys): against a reference above the row's largest score no probability is exactly 1, and a row one key
+//     dominates would carry that key's bf16 rounding (up to 2^-9) into every probability the backward recomputes.
 //   * Operands need no masks: lane groups 1..3 of an A operand fill k-slots 8..31, which meet the zeros of the B operand (the
 //     query row lives in group 0 only), so every lane simply reads its row (the four groups read the same 256 bytes: a broadcast).
 // Per 32 keys and lane: 8 multiplies, 8 exponentials, 4 packed conversions (the first kernel: ~75 vector instructions).
@@ -750,19 +771,29 @@ __global__ __launch_bounds__(512) void pmx_attn8_fwd2_kernel(const __hip_bfloat1
     const size_t row_stride = bm ? (size_t)3 * E : (size_t)B * 3 * E;
     const size_t head_off = (size_t)b * 3 * E * (bm ? S : 1) + (size_t)h * D;
     const size_t out_row = bm ? (size_t)E : (size_t)B * E, out_off = (size_t)b * E * (bm ? S : 1) + (size_t)h * D;
+    float k2max = 0.0f, q2max = 0.0f;                                 // largest squared norms of the head's keys and queries
     for (int s = lane + 64 * role; s < S_pad; s += 128) {
         uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
         if (s < S) {
             kv = *reinterpret_cast<const uint4 *>(base + (size_t)s * row_stride + head_off + E);
             vv = *reinterpret_cast<const uint4 *>(base + (size_t)s * row_stride + head_off + 2 * E);
+            q2max = fmaxf(q2max, sq_norm8(*reinterpret_cast<const uint4 *>(base + (size_t)s * row_stride + head_off)));
         }
         *reinterpret_cast<uint4 *>(Ks + (size_t)s * D) = kv;
         const short *vs = reinterpret_cast<const short *>(&vv);
 #pragma unroll
         for (int d = 0; d < D; ++d) Vt[(size_t)d * S_pad + s] = vs[d];
-        Vt[(size_t)D * S_pad + s] = (short)0x3F80;                  // 1.0
+        Vt[(size_t)D * S_pad + s] = s < S ? (short)0x3F80 : (short)0;          // 1.0 for the real keys
+        k2max = fmaxf(k2max, sq_norm8(kv));
     }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) k2max = fmaxf(k2max, __shfl_xor(k2max, off)), q2max = fmaxf(q2max, __shfl_xor(q2max, off));
+    float *knorm = reinterpret_cast<float *>(reinterpret_cast<short *>(smem) + (size_t)HEADS * (D + 9) * S_pad);     // [8 waves][2]
+    if (lane == 0) knorm[2 * wave] = k2max, knorm[2 * wave + 1] = q2max;
     __syncthreads();
+    // the head's two waves staged alternate blocks of 64 rows.  |q| |k| <= bound for every pair of the head (a hair above: the
+    // root and the products round)
+    const float bound = __builtin_sqrtf(fmaxf(knorm[2 * h], knorm[2 * h + 8]) * fmaxf(knorm[2 * h + 1], knorm[2 * h + 9])) * 1.0001f;
 
     const int g = lane >> 4, c = lane & 15;
     const pmx_bf16x8 zero8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -772,12 +803,21 @@ __global__ __launch_bounds__(512) void pmx_attn8_fwd2_kernel(const __hip_bfloat1
     const short *krow = Ks + (size_t)c * D;                                              // + kp * 32 * D (+ 16 * D)
     const short *vrow = Vt + (size_t)(c < D ? c : D) * S_pad + g * 4;                    // + kp * 32 (+ 16); rows >= 9 of the result are unused
     const int last_lo = S - (n_kp - 1) * 32 - g * 4;               // key index r (resp. 16 + r) of the last pair is real iff r < last_lo (- 16)
+    const bool exact = bound * c2 > 44.0f;                          // (uniform over the head's two waves)
+    pmx_f32x2 real[4];                                              // 1 for the lane's real keys of the last pair, 0 for its padded ones
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r0 = (i & 1) * 2 + (i >> 1) * 16;                 // e[2 i], e[2 i + 1] are keys r0, r0 + 1 (+ 4 g) of the pair
+        real[i] = pmx_f32x2{ r0 < last_lo ? 1.f : 0.f, r0 + 1 < last_lo ? 1.f : 0.f };
+    }
     for (int qt = role; qt < n_qt; qt += 2) {
         const int q_row = qt * 16 + c;
         pmx_bf16x8 qf = zero8;
         if (g == 0 && q_row < S) qf = *reinterpret_cast<const pmx_bf16x8 *>(base + (size_t)q_row * row_stride + head_off);
-        // ---- pass 1: the largest raw score of each query (column c) --------------------------------------------------------
-        float mx = -3.0e38f;
+        float mx = bound;
+        if (exact) {
+        // ---- exact path, pass 1: the largest raw score of each query ------------------------------------------------------
+        mx = -3.0e38f;
 #pragma unroll 2
         for (int kp = 0; kp < n_kp - 1; ++kp) {
             const pmx_bf16x8 k0 = *reinterpret_cast<const pmx_bf16x8 *>(krow + (size_t)kp * 32 * D);
@@ -803,23 +843,41 @@ __global__ __launch_bounds__(512) void pmx_attn8_fwd2_kernel(const __hip_bfloat1
         }
         mx = __builtin_elementwise_maximum(mx, __shfl_xor(mx, 16));
         mx = __builtin_elementwise_maximum(mx, __shfl_xor(mx, 32));
+        }
         // ---- pass 2: O^T (+ the row sums in row 8) against the fixed reference ---------------------------------------------
         const pmx_f32x4 negm = { -mx, -mx, -mx, -mx };
         pmx_f32x4 o = z4;
-        auto tile = [&](int kp, bool last) {
+        pmx_f32x2 ls[2] = { { 0.f, 0.f }, { 0.f, 0.f } };          // the lane's sum of UNROUNDED probabilities, for the log-sum-exp
+        // mode 0: a pair of key tiles without padding.  The last pair may hold padded keys (zero K rows, zero V^T columns INCLUDING the
+        // row of ones: whatever their probability, they add nothing to O or to its normaliser).  Mode 2 (reference = the bound, so
+        // the padded keys' exponent -bound c is <= 0): only the exact row sum must leave them out -- a multiply-add with the lane's 0 / 1
+        // mask instead of the add.  Mode 1 (exact path: the largest score may be far below zero and exp2(-m c) overflow): the padded
+        // probabilities are set to zero by compares, as everywhere before.
+        auto tile = [&](int kp, auto mode_c) {
+            constexpr int mode = decltype(mode_c)::value;
             const pmx_bf16x8 k0 = *reinterpret_cast<const pmx_bf16x8 *>(krow + (size_t)kp * 32 * D);
             const pmx_bf16x8 k1 = *reinterpret_cast<const pmx_bf16x8 *>(krow + (size_t)(kp * 32 + 16) * D);
             const pmx_f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf, negm, 0, 0, 0);     // s - m
             const pmx_f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf, negm, 0, 0, 0);
+            const pmx_f32x2 cc = { c2, c2 };
+            const pmx_f32x2 x[4] = { pmx_f32x2{ s0[0], s0[1] } * cc, pmx_f32x2{ s0[2], s0[3] } * cc, pmx_f32x2{ s1[0], s1[1] } * cc,
+                                     pmx_f32x2{ s1[2], s1[3] } * cc };                            // (packed multiplies)
             float e[8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                e[r] = __builtin_amdgcn_exp2f(s0[r] * c2);
-                e[4 + r] = __builtin_amdgcn_exp2f(s1[r] * c2);
-                if (last) {                                            // padded keys take no part
+            for (int r = 0; r < 8; ++r) e[r] = __builtin_amdgcn_exp2f(x[r >> 1][r & 1]);
+            if constexpr (mode == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
                     if (r >= last_lo) e[r] = 0.f;
                     if (r + 16 >= last_lo) e[4 + r] = 0.f;
                 }
+            }
+            if constexpr (mode == 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ls[i & 1] = __builtin_elementwise_fma(pmx_f32x2{ e[2 * i], e[2 * i + 1] }, real[i], ls[i & 1]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ls[i & 1] += pmx_f32x2{ e[2 * i], e[2 * i + 1] };
             }
             pmx_bf16x8 pf;
 #pragma unroll
@@ -831,8 +889,12 @@ __global__ __launch_bounds__(512) void pmx_attn8_fwd2_kernel(const __hip_bfloat1
             o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const pmx_bf16x8 *>(&both), pf, o, 0, 0, 0);
         };
 #pragma unroll 2
-        for (int kp = 0; kp < n_kp - 1; ++kp) tile(kp, false);
-        tile(n_kp - 1, true);
+        for (int kp = 0; kp < n_kp - 1; ++kp) tile(kp, std::integral_constant<int, 0>{});
+        if (exact) tile(n_kp - 1, std::integral_constant<int, 1>{});
+        else tile(n_kp - 1, std::integral_constant<int, 2>{});
+        float lx = (ls[0][0] + ls[0][1]) + (ls[1][0] + ls[1][1]);   // the four lane groups hold different keys of query c
+        lx += __shfl_xor(lx, 16);
+        lx += __shfl_xor(lx, 32);
         // O^T[row 4g + r][query c]: groups 0 and 1 hold d = 0..3 and 4..7, group 2 holds the row sums in r = 0
         const float l = __shfl(o[0], 32 + c);
         if (q_row < S) {
@@ -844,7 +906,7 @@ __global__ __launch_bounds__(512) void pmx_attn8_fwd2_kernel(const __hip_bfloat1
                 *reinterpret_cast<uint2 *>(reinterpret_cast<short *>(out) + (size_t)q_row * out_row + out_off + g * 4) =
                     *reinterpret_cast<const uint2 *>(w4);
             }
-            if (g == 0 && lse) lse[((size_t)b * HEADS + h) * S + q_row] = (mx * c2 + __log2f(l)) * 0.69314718055994531f;   // natural log
+            if (g == 0 && lse) lse[((size_t)b * HEADS + h) * S + q_row] = (mx * c2 + __log2f(lx)) * 0.69314718055994531f;  // natural log
         }
     }
 }
@@ -865,7 +927,7 @@ extern "C" int pmx_attn8_forward_layout(const void *qkv_dev, void *out_dev, floa
     if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev < 0 || cur_dev >= 64) return PMX_ERR_HIP;
     static const bool v1 = getenv("PMX_ATTN_FWD_V1") != nullptr;                    // A/B switch, read once
     if (!v1) {
-        const size_t lds2 = (size_t)4 * (8 + 9) * S_pad * sizeof(short);
+        const size_t lds2 = (size_t)4 * (8 + 9) * S_pad * sizeof(short) + 16 * sizeof(float);
         static bool attr2_dev[64] = {};
         if (lds2 > 65536 && !attr2_dev[cur_dev]) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(pmx_attn8_fwd2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)

@@ -339,21 +339,23 @@ def test_mfma_attention_forward_matches_torch(S, B):
     assert float((lse - torch.logsumexp(sc, -1)).abs().max()) <= 2e-3
 
 
-def test_mfma_attention_forward_with_large_and_shifted_scores():
-    """The forward kernel exponentiates against each query's exact largest raw score (found in a first pass over the keys): scores
-    of +-50 .. 300 and rows whose scores are ALL far below zero (a common component in every key, as an in-projection bias produces)
-    must neither overflow nor underflow."""
+@pytest.mark.parametrize("amp,shift,far", [(4.0, -25.0, 50.0), (1.5, -5.0, 3.0)])
+def test_mfma_attention_forward_with_large_and_shifted_scores(amp, shift, far):
+    """The forward kernel exponentiates against a reference fixed per query before the loop over the keys: the bound |q| max |k|
+    while that is small enough for every row's largest probability to stay a normal number (second case: rows whose scores ALL
+    sit far below the bound -- a common component in every key, as an in-projection bias produces), the exact largest score found
+    in a first pass otherwise (first case: scores of +-50 .. 300).  Neither may overflow or underflow."""
     from pmx import mappo
     torch.manual_seed(77)
     S, B = 154, 6
-    x = torch.randn(S, B, 96, device="cuda") * 4.0
-    x[:, :, 32:64] += -25.0 * torch.sign(x[:1, :, 0:32])           # every key carries a large component opposed to the FIRST query's signs
+    x = torch.randn(S, B, 96, device="cuda") * amp
+    x[:, :, 32:64] += shift * torch.sign(x[:1, :, 0:32])           # every key carries a large component opposed to the FIRST query's signs
     qkv = x.to(torch.bfloat16)
     out, lse = mappo.attention8_forward(qkv, want_lse=True)
     q, k, v = qkv.float().chunk(3, dim=-1)
     q, k, v = (t.reshape(S, B, 4, 8).permute(1, 2, 0, 3) for t in (q, k, v))
     sc = torch.matmul(q, k.transpose(-1, -2)) / 8 ** 0.5
-    assert float(sc[:, :, 0].max()) < -50.0 and float(sc.max()) > 50.0         # rows far below zero and rows far above exist
+    assert float(sc[:, :, 0].max()) < -far and float(sc.max()) > far           # rows far below zero and rows far above exist
     ref = torch.matmul(torch.softmax(sc, -1), v).permute(2, 0, 1, 3).reshape(S, B, 32)
     assert bool(torch.isfinite(out.float()).all()) and bool(torch.isfinite(lse).all())
     assert float((out.float() - ref).abs().max()) <= 2e-2 * (float(ref.abs().max()) + 1e-6)
