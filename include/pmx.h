@@ -298,6 +298,14 @@ int pmx_set_floats(float *dst_dev, const float *values, int32_t n, void *stream)
 int pmx_clip_adam_ema(float *grad_dev, float *param_dev, float *exp_avg_dev, float *exp_avg_sq_dev, float *ema_dev, int64_t n,
                       double *scratch_dev, const float *scalars_dev, float lr_over_bc1, float rsqrt_bc2, float beta1, float beta2,
                       float eps, float max_norm, float ema_decay, float *norm_out_dev, void *stream);
+/* The same two launches with the step's loose ends folded into the second one (each pointer may be NULL): param_bf16_dev receives
+ * the updated parameters rounded to bfloat16 (n elements: the copy library GEMMs read under autocast); report_sums6_dev[0..4] +=
+ * reports5_dev[0..4] (the objective's five scalars, pmx_ppo_loss) and report_sums6_dev[5] += the gradient norm -- the running sums
+ * a caller averages over an update.  Three small launches less at the end of a replayed 512-sample step. */
+int pmx_clip_adam_ema_tail(float *grad_dev, float *param_dev, float *exp_avg_dev, float *exp_avg_sq_dev, float *ema_dev, int64_t n,
+                           double *scratch_dev, const float *scalars_dev, float lr_over_bc1, float rsqrt_bc2, float beta1, float beta2,
+                           float eps, float max_norm, float ema_decay, float *norm_out_dev, void *param_bf16_dev,
+                           const float *reports5_dev, float *report_sums6_dev, void *stream);
 
 /* n contiguous device tensors (float32, or bfloat16 where src_is_bf16[t]) copied / widened into dst_dev at element offsets
  * dst_offset[t], count[t] elements each, one launch per 64 tensors: the parameter gradients of a step into the flat float32

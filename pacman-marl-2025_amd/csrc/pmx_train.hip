@@ -1918,7 +1918,9 @@ __global__ __launch_bounds__(256) void pmx_adam_ema_kernel(float *__restrict__ g
                                                            float *__restrict__ v, float *__restrict__ ema, long n,
                                                            const double *__restrict__ partial, int n_partial, const float *sc_dev,
                                                            float lr_bc1_host, float rsqrt_bc2_host, float b1, float b2, float eps,
-                                                           float max_norm, float decay, float *__restrict__ norm_out)
+                                                           float max_norm, float decay, float *__restrict__ norm_out,
+                                                           uint16_t *__restrict__ p_bf16, const float *__restrict__ reports5,
+                                                           float *__restrict__ report_sums6)
 {
     __shared__ double red[4];
     __shared__ float s_scale;
@@ -1932,6 +1934,13 @@ __global__ __launch_bounds__(256) void pmx_adam_ema_kernel(float *__restrict__ g
         const float norm = (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
         s_scale = fminf(max_norm / (norm + 1e-6f), 1.0f);
         if (blockIdx.x == 0 && norm_out) *norm_out = norm;
+        if (blockIdx.x == 0 && report_sums6) {             // running sums of the step's reports, for the caller's averages
+            if (reports5) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) report_sums6[k] += reports5[k];
+            }
+            report_sums6[5] += norm;
+        }
     }
     __syncthreads();
     const float scale = s_scale;
@@ -1944,12 +1953,21 @@ __global__ __launch_bounds__(256) void pmx_adam_ema_kernel(float *__restrict__ g
         const float pi = p[i] - lr_bc1 * (mi / denom);
         g[i] = gi; m[i] = mi; v[i] = vi; p[i] = pi;
         ema[i] = ema[i] * decay + pi * (1.0f - decay);
+        if (p_bf16) p_bf16[i] = (uint16_t)pmx_f2bf(pi);     // the bfloat16 copy the library GEMMs read (round to nearest even)
     }
 }
 
 extern "C" int pmx_clip_adam_ema(float *grad_dev, float *param_dev, float *exp_avg_dev, float *exp_avg_sq_dev, float *ema_dev, int64_t n,
                                  double *scratch_dev, const float *scalars_dev, float lr_over_bc1, float rsqrt_bc2, float beta1, float beta2,
                                  float eps, float max_norm, float ema_decay, float *norm_out_dev, void *stream)
+{
+    return pmx_clip_adam_ema_tail(grad_dev, param_dev, exp_avg_dev, exp_avg_sq_dev, ema_dev, n, scratch_dev, scalars_dev, lr_over_bc1, rsqrt_bc2,
+                                  beta1, beta2, eps, max_norm, ema_decay, norm_out_dev, nullptr, nullptr, nullptr, stream);
+}
+extern "C" int pmx_clip_adam_ema_tail(float *grad_dev, float *param_dev, float *exp_avg_dev, float *exp_avg_sq_dev, float *ema_dev, int64_t n,
+                                      double *scratch_dev, const float *scalars_dev, float lr_over_bc1, float rsqrt_bc2, float beta1,
+                                      float beta2, float eps, float max_norm, float ema_decay, float *norm_out_dev, void *param_bf16_dev,
+                                      const float *reports5_dev, float *report_sums6_dev, void *stream)
 {
     if (!grad_dev || !param_dev || !exp_avg_dev || !exp_avg_sq_dev || !ema_dev || !scratch_dev || n < 1) return PMX_ERR_INVALID;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1961,7 +1979,7 @@ extern "C" int pmx_clip_adam_ema(float *grad_dev, float *param_dev, float *exp_a
     if (b2k > 2048) b2k = 2048;
     hipLaunchKernelGGL(pmx_adam_ema_kernel, dim3((unsigned)b2k), dim3(256), 0, st, grad_dev, param_dev, exp_avg_dev, exp_avg_sq_dev, ema_dev, (long)n,
                        (const double *)scratch_dev, (int)blocks, scalars_dev, lr_over_bc1, rsqrt_bc2, beta1, beta2, eps, max_norm, ema_decay,
-                       norm_out_dev);
+                       norm_out_dev, (uint16_t *)param_bf16_dev, reports5_dev, report_sums6_dev);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;
 }
 

@@ -928,8 +928,34 @@ class _PPOLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gstats):
         dlogits, dvalues = ctx.saved_tensors
+        unit = _UNIT5.get(_dev_key(gstats.device))
+        if unit is not None and gstats.data_ptr() == unit.data_ptr():
+            return dlogits, dvalues, None, None, None, None, None, None, None      # d(loss) = 1: the kernel's gradients as they are
         g = gstats[4]                                     # only the total loss is an objective; the other entries are reports
         return dlogits * g.to(dlogits.dtype), dvalues * g, None, None, None, None, None, None, None
+
+
+# Differentiating `loss = stats[4]` costs five small launches before the first real backward kernel (a one for the root, a zero
+# 5-vector and the copy of the one into it for the select, two scalings of the kernel's gradients by it) -- 27 us on the critical
+# path of a 540 us step.  The learner differentiates the 5-vector itself against this constant [0, 0, 0, 0, 1] instead
+# (loss_root), and the backward above recognises it by address.
+_UNIT5 = {}
+
+
+def _dev_key(dev):
+    return (dev.type, dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == "cuda" else 0))
+
+
+def loss_root(loss):
+    """(tensor to differentiate, grad_outputs) for a loss returned by ppo_loss: the fused objective's 5-vector with the unit
+    gradient where the loss came from the fused kernel, the loss itself otherwise."""
+    stats = getattr(loss, "_pmx_stats", None)
+    if stats is None:
+        return loss, None
+    key = _dev_key(stats.device)
+    if key not in _UNIT5:
+        _UNIT5[key] = torch.tensor([0.0, 0.0, 0.0, 0.0, 1.0], dtype=torch.float32, device=stats.device)
+    return stats, _UNIT5[key]
 
 
 _SIDE_STREAMS = {}
@@ -971,7 +997,9 @@ def ppo_loss(model, obs, merged, act, old_logp, adv, ret, clip_eps, ent_coef, vf
             logits = logits.float()
         stats = _PPOLossFn.apply(logits, vals, act, old_logp, adv, ret, clip_eps, ent_coef, vf_coef)
         d = stats.detach()
-        return stats[4], {"pg": d[0], "vl": d[1], "entropy": d[2], "clip_frac": d[3], "loss": d[4]}
+        loss = stats[4]
+        loss._pmx_stats = stats                           # (loss_root: what the learner differentiates instead of the select)
+        return loss, {"pg": d[0], "vl": d[1], "entropy": d[2], "clip_frac": d[3], "loss": d[4]}
     vals, logp, ent = model.evaluate(obs, merged, act)
     if vals.shape[0] != ret.shape[0]:
         # paired minibatch: rows 2k and 2k+1 are the two learners of one env-tick and share ONE merged critic input
@@ -1105,8 +1133,9 @@ class PPOLearner:
                     targets[i - lo] = v                  # the bfloat16 copy the library op multiplied by
         dev = self.bucket.grad.device
         prev, _DEFER_ROW_SUMS[0] = _DEFER_ROW_SUMS[0], bool(self.defer_row_sums and dev.type == "cuda")
+        root, unit = loss_root(loss)
         try:
-            grads = torch.autograd.grad(loss, targets, allow_unused=True, retain_graph=retain)
+            grads = torch.autograd.grad(root, targets, grad_outputs=unit, allow_unused=True, retain_graph=retain)
         finally:
             _DEFER_ROW_SUMS[0] = prev
         if dev.type == "cuda":
@@ -1154,7 +1183,8 @@ class PPOLearner:
         """The backward pass with the gradient ending up in the flat float32 bucket and, under data parallelism, averaged over the
         ranks: group by group, each group's all-reduce in flight while the next group's backward runs."""
         if self._w16 is not None:
-            (g16,) = torch.autograd.grad(loss, (self._w16,))
+            root, unit = loss_root(loss)
+            (g16,) = torch.autograd.grad(root, (self._w16,), grad_outputs=unit)
             self.bucket.grad.copy_(g16)
             if self.dp:
                 self._reduce_slice(0, len(self.bucket.params))()
@@ -1169,6 +1199,9 @@ class PPOLearner:
             fin()
 
     def _refresh_bf16(self):
+        if getattr(self, "_bf16_fresh", False):               # the optimizer kernel has just written the (one) copy
+            self._bf16_fresh = False
+            return
         if self._w16 is not None:
             with torch.no_grad():
                 self._w16.copy_(self.bucket.data)
@@ -1233,10 +1266,11 @@ class PPOLearner:
 
     fused_optimizer = True   # clip + Adam + EMA as two launches on the GPU (pmx_clip_adam_ema) instead of ~18 torch kernels
 
-    def _fused_tail(self, scalars_dev=None):
-        """clip_grad_norm_ -> Adam -> EMA through pmx_clip_adam_ema; returns the gradient norm (a 0-dim device tensor).  With
+    def _fused_tail(self, scalars_dev=None, reports5=None, report_sums6=None):
+        """clip_grad_norm_ -> Adam -> EMA through pmx_clip_adam_ema_tail; returns the gradient norm (a 0-dim device tensor).  With
         scalars_dev the bias-corrected step sizes are read from that device tensor (graph replay), else computed here from
-        step_count, which the caller has already advanced."""
+        step_count, which the caller has already advanced.  The same launch refreshes the bfloat16 copy of the parameters (where
+        there is exactly one) and, given report_sums6, adds the objective's five scalars and the gradient norm to it."""
         import ctypes as C
         from . import _lib
         lib = _lib.load()
@@ -1251,9 +1285,15 @@ class PPOLearner:
         else:
             sp, a, b = scalars_dev.data_ptr(), 0.0, 0.0
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(lib.pmx_clip_adam_ema(self.bucket.grad.data_ptr(), self.bucket.data.data_ptr(), self.exp_avg.data_ptr(),
-                                         self.exp_avg_sq.data_ptr(), self.ema.data_ptr(), self.bucket.numel, self._opt_scratch.data_ptr(), sp,
-                                         a, b, b1, b2, self.eps, MAX_GRAD_NORM, EMA_DECAY, self._opt_norm.data_ptr(), st), "pmx_clip_adam_ema")
+        copies = [t for t in (self._w16, self._sh16) if t is not None]
+        p16 = copies[0] if len(copies) == 1 and copies[0].is_contiguous() and copies[0].numel() == self.bucket.numel else None
+        _lib.check(lib.pmx_clip_adam_ema_tail(self.bucket.grad.data_ptr(), self.bucket.data.data_ptr(), self.exp_avg.data_ptr(),
+                                              self.exp_avg_sq.data_ptr(), self.ema.data_ptr(), self.bucket.numel, self._opt_scratch.data_ptr(),
+                                              sp, a, b, b1, b2, self.eps, MAX_GRAD_NORM, EMA_DECAY, self._opt_norm.data_ptr(),
+                                              p16.data_ptr() if p16 is not None else None,
+                                              reports5.data_ptr() if reports5 is not None else None,
+                                              report_sums6.data_ptr() if report_sums6 is not None else None, st), "pmx_clip_adam_ema_tail")
+        self._bf16_fresh = p16 is not None
         return self._opt_norm[0]
 
     def _use_fused_tail(self):
@@ -1330,9 +1370,14 @@ class PPOLearner:
                                        self._g_sc[2], self._g_sc[3])
             return loss, stats
 
+        REPORTS = ("pg", "vl", "entropy", "clip_frac", "loss")
+
         def seg_tail(stats):
+            # the fused objective's 5-vector (ppo_loss leaves it on the loss): with it the optimizer kernel keeps the running sums
+            s5 = getattr(state.get("loss"), "_pmx_stats", None)
+            in_kernel = self._use_fused_tail() and s5 is not None and tuple(stats.keys()) == REPORTS and s5.dtype == torch.float32
             if self._use_fused_tail():
-                gn = self._fused_tail(self._g_sc)
+                gn = self._fused_tail(self._g_sc, *((s5.detach(), self._g_acc) if in_kernel else ()))
             else:
                 self._g_norms = torch.stack(torch._foreach_norm([p.grad for p in self.bucket.params]))   # kept: per-tensor norms
                 gn = torch.linalg.vector_norm(self._g_norms)
@@ -1349,7 +1394,8 @@ class PPOLearner:
             # running sums of the step's reports, inside the graph: a caller that averages them over an update reads ONE tensor at
             # the end instead of launching an add per report and step
             self._g_acc_keys = tuple(stats.keys())
-            self._g_acc.add_(torch.stack([stats[k].float() for k in self._g_acc_keys]))
+            if not in_kernel:
+                self._g_acc.add_(torch.stack([stats[k].float() for k in self._g_acc_keys]))
             return stats
 
         # Data parallel: the collectives stay OUTSIDE the graphs (eager RCCL calls, exactly the ones the eager step issues), so
@@ -1370,7 +1416,8 @@ class PPOLearner:
         def seg_first():
             state["loss"], state["stats"] = seg_loss()
             if self._w16 is not None:
-                (g16,) = torch.autograd.grad(state["loss"], (self._w16,))
+                root, unit = loss_root(state["loss"])
+                (g16,) = torch.autograd.grad(root, (self._w16,), grad_outputs=unit)
                 self.bucket.grad.copy_(g16)
             else:
                 self._backward_group(state["loss"], *groups[0], retain=len(groups) > 1)
