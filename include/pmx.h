@@ -312,6 +312,11 @@ int pmx_clip_adam_ema_tail(float *grad_dev, float *param_dev, float *exp_avg_dev
  * gradient bucket.  The four arrays are HOST arrays. */
 int pmx_flatten_to_f32(int32_t n, const void *const *src_dev, const uint8_t *src_is_bf16, const int64_t *dst_offset,
                        const int32_t *count, float *dst_dev, void *stream);
+/* The same with the second stage of the gradient reductions folded in: where partial_rows[t] > 0, src_dev[t] points into row 0 of a
+ * float32 partial-row buffer (pmx_defer_row_sums) whose rows 1 .. partial_rows[t] lie row_stride[t] floats apart, and the
+ * destination receives their sum.  partial_rows / row_stride: HOST arrays, or both NULL. */
+int pmx_flatten_sum_to_f32(int32_t n, const void *const *src_dev, const uint8_t *src_is_bf16, const int32_t *partial_rows,
+                           const int32_t *row_stride, const int64_t *dst_offset, const int32_t *count, float *dst_dev, void *stream);
 
 /* ---- The actor's convolutional tower as one forward and one backward kernel ------------------------------------------
  * MAPPOAgent.actor_backbone (pacman_mappo_resnet.py:104-113 with ResidualBlock :49-67):

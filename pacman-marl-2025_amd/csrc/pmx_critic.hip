@@ -825,6 +825,7 @@ extern "C" int pmx_ffn_backward(const void *x_dev, const void *dy_dev, const voi
 {
     if (!grad_dev) return PMX_ERR_INVALID;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    pmx_last_rows_value = 0;                                  // (row 0 is final on every path that launches no partial rows)
     if (tokens == 0) return hipMemsetAsync(grad_dev, 0, sizeof(float) * G_FLOATS, st) == hipSuccess ? PMX_OK : PMX_ERR_HIP;
     if (!x_dev || !dy_dev || !pack_dev || !dx_dev || tokens < 0) return PMX_ERR_INVALID;
     const size_t lds = (size_t)4 * 32 * STG_ROW;
@@ -864,6 +865,7 @@ int tok_backward(const void *a, const void *x, const void *dy, const void *pack,
                  hipStream_t st)
 {
     if (!grad) return PMX_ERR_INVALID;
+    pmx_last_rows_value = 0;
     if (tokens == 0) return hipMemsetAsync(grad, 0, sizeof(float) * TokPack<NP>::G_FLOATS, st) == hipSuccess ? PMX_OK : PMX_ERR_HIP;
     if (!a || !dy || !pack || !da || (LN && (!x || !dx)) || tokens < 0) return PMX_ERR_INVALID;
     const size_t stage = (size_t)4 * 32 * tok_stg_row<NP>(), reduce = (size_t)4 * 4 * NP * 1024 + 4096;   // staging areas, then the block-level sums

@@ -442,6 +442,7 @@ extern "C" int pmx_actor_tail_backward(const void *h_dev, int32_t h_bf16, const 
 {
     if (!grad_dev || B < 0) return PMX_ERR_INVALID;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    pmx_last_rows_value = 0;
     if (B == 0) return hipMemsetAsync(grad_dev, 0, sizeof(float) * AT_FLOATS, st) == hipSuccess ? PMX_OK : PMX_ERR_HIP;
     if (!h_dev || !stats_dev || !dlogits_dev || !ln_w || !ln_b || !w2 || !dh_dev) return PMX_ERR_INVALID;
     const int blocks = heads_blocks(B, PMX_HEADS_PARTIAL_ROWS);
@@ -489,6 +490,7 @@ extern "C" int pmx_critic_tail_backward(const float *pooled_dev, const float *dv
 {
     if (!grad_dev || B < 0) return PMX_ERR_INVALID;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    pmx_last_rows_value = 0;
     if (B == 0) return hipMemsetAsync(grad_dev, 0, sizeof(float) * CT_FLOATS, st) == hipSuccess ? PMX_OK : PMX_ERR_HIP;
     if (!pooled_dev || !dvalue_dev || !w1 || !b1 || !w2 || !dtokens_dev || !scratch_dev || S < 1) return PMX_ERR_INVALID;
     __hip_bfloat16 *dh = reinterpret_cast<__hip_bfloat16 *>(scratch_dev), *g = dh + (size_t)B * HID;       // scratch: 2 x B x 512 bf16

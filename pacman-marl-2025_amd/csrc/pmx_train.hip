@@ -1993,6 +1993,8 @@ struct PmxFlattenArgs {
     const void *src[PMX_FLATTEN_MAX];
     int64_t off[PMX_FLATTEN_MAX];
     int32_t count[PMX_FLATTEN_MAX];
+    int32_t rows[PMX_FLATTEN_MAX];                 // > 0: the source is rows 1 .. rows of a partial-row buffer (stride floats apart) still to be added
+    int32_t stride[PMX_FLATTEN_MAX];
     uint8_t bf16[PMX_FLATTEN_MAX];
 };
 __global__ __launch_bounds__(256) void pmx_flatten_f32_kernel(PmxFlattenArgs a, float *__restrict__ dst)
@@ -2000,7 +2002,37 @@ __global__ __launch_bounds__(256) void pmx_flatten_f32_kernel(PmxFlattenArgs a, 
     const int t = blockIdx.y;
     const int n = a.count[t];
     float *d = dst + a.off[t];
-    if (a.bf16[t]) {
+    if (a.rows[t] > 0) {
+        // the second stage of a gradient reduction, done here instead of by a launch of its own behind the backward kernel: s points
+        // into row 0 of the buffer, the partial rows follow `stride` floats apart.  As pmx_sum_rows_kernel does it: a block takes 32
+        // columns with 8 slices of the rows side by side (four loads in flight per thread) and adds the slices through LDS.
+        __shared__ float part[8][33];
+        const float *s = reinterpret_cast<const float *>(a.src[t]);
+        const int rows = a.rows[t];
+        const size_t st = (size_t)a.stride[t];
+        const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
+        for (int c0 = blockIdx.x * 32; c0 < n; c0 += gridDim.x * 32) {             // (uniform over the block)
+            const int i = c0 + c;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            if (i < n) {
+                int r = 1 + sl;
+                for (; r + 24 <= rows; r += 32) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[k] += s[(size_t)(r + 8 * k) * st + i];
+                }
+                for (; r <= rows; r += 8) acc[0] += s[(size_t)r * st + i];
+            }
+            part[sl][c] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            __syncthreads();
+            if (sl == 0 && i < n) {
+                float tt = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) tt += part[k][c];
+                d[i] = tt;
+            }
+            __syncthreads();
+        }
+    } else if (a.bf16[t]) {
         const uint16_t *s = reinterpret_cast<const uint16_t *>(a.src[t]);
         for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) d[i] = __uint_as_float((uint32_t)s[i] << 16);
     } else {
@@ -2011,7 +2043,14 @@ __global__ __launch_bounds__(256) void pmx_flatten_f32_kernel(PmxFlattenArgs a, 
 extern "C" int pmx_flatten_to_f32(int32_t n, const void *const *src_dev, const uint8_t *src_is_bf16, const int64_t *dst_offset,
                                   const int32_t *count, float *dst_dev, void *stream)
 {
-    if (n < 1 || !src_dev || !src_is_bf16 || !dst_offset || !count || !dst_dev) return PMX_ERR_INVALID;
+    return pmx_flatten_sum_to_f32(n, src_dev, src_is_bf16, nullptr, nullptr, dst_offset, count, dst_dev, stream);
+}
+extern "C" int pmx_flatten_sum_to_f32(int32_t n, const void *const *src_dev, const uint8_t *src_is_bf16, const int32_t *partial_rows,
+                                      const int32_t *row_stride, const int64_t *dst_offset, const int32_t *count, float *dst_dev,
+                                      void *stream)
+{
+    if (n < 1 || !src_dev || !src_is_bf16 || !dst_offset || !count || !dst_dev || ((partial_rows != nullptr) != (row_stride != nullptr)))
+        return PMX_ERR_INVALID;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     for (int base = 0; base < n; base += PMX_FLATTEN_MAX) {
         const int m = n - base < PMX_FLATTEN_MAX ? n - base : PMX_FLATTEN_MAX;
@@ -2021,6 +2060,10 @@ extern "C" int pmx_flatten_to_f32(int32_t n, const void *const *src_dev, const u
         for (int t = 0; t < m; ++t) {
             if (!src_dev[base + t] || count[base + t] < 0 || dst_offset[base + t] < 0) return PMX_ERR_INVALID;
             a.src[t] = src_dev[base + t]; a.off[t] = dst_offset[base + t]; a.count[t] = count[base + t]; a.bf16[t] = src_is_bf16[base + t] ? 1 : 0;
+            if (partial_rows && partial_rows[base + t] > 0) {
+                if (a.bf16[t] || row_stride[base + t] < count[base + t]) return PMX_ERR_INVALID;
+                a.rows[t] = partial_rows[base + t]; a.stride[t] = row_stride[base + t];
+            }
             most = count[base + t] > most ? count[base + t] : most;
         }
         int blocks = (most + 2047) / 2048;                     // ~8 elements per thread for the largest tensor

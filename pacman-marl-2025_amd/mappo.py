@@ -34,20 +34,21 @@ def layer_norm_small(x, ln):
     return ((xf - mean) * torch.rsqrt(var + ln.eps) * ln.weight + ln.bias).to(x.dtype)
 
 
-_SUM_STREAMS, _SUMS_PENDING = {}, set()
-_DEFER_ROW_SUMS = [False]  # True only while PPOLearner._backward_group runs autograd (it joins the side stream before it reads the
-                           # gradients); any other caller of these autograd functions gets the summed row on its own stream
+_PENDING_ROWS = {}          # data_ptr of a partial-row gradient buffer -> (rows still to be added, floats per row, the buffer)
+_DEFER_ROW_SUMS = [False]  # True only while PPOLearner._backward_group runs autograd: its gradient gather adds the rows; any other
+                           # caller of these autograd functions gets the summed row from the backward call itself
 
 
 class _row_sums_deferred:
-    """Context for ONE backward call of the pmx_ffn / tok96 / tok32ln / *_tail families: the library skips the small row-sum kernel
-    that ends it, and on exit the rows are added on a per-device side stream instead -- beside the next backward kernel of the
-    chain rather than in front of it.  The consumer of the summed row (the gradient gather of PPOLearner._backward_group, or
-    join_row_sums()) waits for that stream."""
+    """Context for ONE backward call of the pmx_ffn / tok96 / tok32ln / *_tail families.  Those end with a small second-stage kernel
+    that adds the partial rows of the parameter gradients into row 0 -- a launch on the critic's chain of the launch-bound
+    512-sample step between every two backward kernels, although nothing before the gradient gather reads its result.  Under
+    PPOLearner._backward_group the library skips that kernel and the buffer is remembered here; the gather (pmx_flatten_sum_to_f32)
+    adds the rows while it copies.  `plain`: the parameter gradients are handed out as float32 views of row 0 (no cast copies)."""
 
-    def __init__(self, lib, grad, floats):
+    def __init__(self, lib, grad, floats, plain=True):
         self.lib, self.grad, self.floats = lib, grad, floats
-        self.on = _DEFER_ROW_SUMS[0] and grad.is_cuda
+        self.on = _DEFER_ROW_SUMS[0] and grad.is_cuda and plain
 
     def __enter__(self):
         if self.on:
@@ -60,26 +61,27 @@ class _row_sums_deferred:
         self.lib.pmx_defer_row_sums(0)
         n = self.lib.pmx_last_partial_rows()
         if exc[0] is None and n > 0:
-            import ctypes as C
-            from . import _lib
-            dev = self.grad.device
-            key = dev.index if dev.index is not None else torch.cuda.current_device()
-            ss = _SUM_STREAMS.get(key)
-            if ss is None:
-                ss = _SUM_STREAMS[key] = torch.cuda.Stream(device=dev)
-            ss.wait_stream(torch.cuda.current_stream(dev))
-            _lib.check(self.lib.pmx_sum_partial_rows(self.grad.data_ptr(), n, self.floats, C.c_void_p(ss.cuda_stream)), "pmx_sum_partial_rows")
-            self.grad.record_stream(ss)
-            _SUMS_PENDING.add(key)
+            _PENDING_ROWS[self.grad.data_ptr()] = (n, self.floats, self.grad)
         return False
 
 
-def join_row_sums(dev):
-    """Makes the current stream wait for the row sums issued on the side stream (no-op when none are pending)."""
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    if key in _SUMS_PENDING:
-        torch.cuda.current_stream(dev).wait_stream(_SUM_STREAMS[key])
-        _SUMS_PENDING.discard(key)
+def pending_rows_of(ptr):
+    """(rows, floats per row) if the device address lies in row 0 of a buffer whose partial rows are still to be added, else (0, 0)."""
+    for base, (n, floats, _) in _PENDING_ROWS.items():
+        if base <= ptr < base + 4 * floats:
+            return n, floats
+    return 0, 0
+
+
+def flush_pending_rows():
+    """Adds whatever partial rows are still pending with the dedicated kernel (a consumer other than the learner's gather)."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load() if _PENDING_ROWS else None
+    for base, (n, floats, buf) in list(_PENDING_ROWS.items()):
+        st = C.c_void_p(torch.cuda.current_stream(buf.device).cuda_stream)
+        _lib.check(lib.pmx_sum_partial_rows(base, n, floats, st), "pmx_sum_partial_rows")
+    _PENDING_ROWS.clear()
 
 
 class _LN32Residual(torch.autograd.Function):
@@ -160,7 +162,7 @@ class _FFNLayerNorm(torch.autograd.Function):
         dy = dy.to(torch.bfloat16).contiguous()
         dx = torch.empty_like(x)
         grad = torch.empty((1 + _lib.GRAD_PARTIAL_ROWS) * _lib.FFN_GRAD_FLOATS, dtype=torch.float32, device=dev)   # row 0 = the result
-        with _row_sums_deferred(lib, grad, _lib.FFN_GRAD_FLOATS):
+        with _row_sums_deferred(lib, grad, _lib.FFN_GRAD_FLOATS, all(dt == torch.float32 for dt in ctx.dtypes)):
             _lib.check(lib.pmx_ffn_backward(x.data_ptr(), dy.data_ptr(), pack.data_ptr(), dx.data_ptr(), grad.data_ptr(), x.numel() // 32,
                                             ctx.eps, st), "pmx_ffn_backward")
         dw2, dw1 = grad[:4096].view(32, 128), grad[4096:8192].view(128, 32)
@@ -259,7 +261,7 @@ class _InProj96(torch.autograd.Function):
         dy = dy.to(torch.bfloat16).contiguous()
         da = torch.empty_like(a)
         grad = torch.empty((1 + _lib.GRAD_PARTIAL_ROWS) * _lib.TOK96_GRAD_FLOATS, dtype=torch.float32, device=a.device)
-        with _row_sums_deferred(lib, grad, _lib.TOK96_GRAD_FLOATS):
+        with _row_sums_deferred(lib, grad, _lib.TOK96_GRAD_FLOATS, all(dt == torch.float32 for dt in ctx.dtypes)):
             _lib.check(lib.pmx_tok96_backward(a.data_ptr(), dy.data_ptr(), pack.data_ptr(), da.data_ptr(), grad.data_ptr(), a.numel() // 32, st),
                        "pmx_tok96_backward")
         return da, grad[:3072].view(96, 32).to(ctx.dtypes[0]), grad[3072:3168].to(ctx.dtypes[1]), None
@@ -295,7 +297,7 @@ class _OutProjAddLN(torch.autograd.Function):
         dy = dy.to(torch.bfloat16).contiguous()
         dx, da = torch.empty_like(x), torch.empty_like(a)
         grad = torch.empty((1 + _lib.GRAD_PARTIAL_ROWS) * _lib.TOK32_GRAD_FLOATS, dtype=torch.float32, device=a.device)
-        with _row_sums_deferred(lib, grad, _lib.TOK32_GRAD_FLOATS):
+        with _row_sums_deferred(lib, grad, _lib.TOK32_GRAD_FLOATS, all(dt == torch.float32 for dt in ctx.dtypes)):
             _lib.check(lib.pmx_tok32ln_backward(x.data_ptr(), a.data_ptr(), dy.data_ptr(), pack.data_ptr(), dx.data_ptr(), da.data_ptr(),
                                                 grad.data_ptr(), x.numel() // 32, ctx.eps, st), "pmx_tok32ln_backward")
         outs = (grad[:1024].view(32, 32), grad[1024:1056], grad[1056:1088], grad[1088:1120])
@@ -1096,10 +1098,11 @@ class PPOLearner:
         fm = SimpleNamespace(evaluate=lambda o, m, a: torch.func.functional_call(self.model, pd, (o, m, a)))
         return ppo_loss(fm, obs, merged, act, old_logp, adv, ret, clip_eps, ent_coef)
 
-    # the second-stage row sums of the gradient reductions on a side stream (mappo._row_sums_deferred).  OFF: measured in the replayed
-    # 512-sample step it LOSES -- 1 380 against 1 995 steps/s; the six fork / join pairs cost the captured graph more than the six
-    # small kernels cost the critic's chain (tools/r03_iso2.sh).  PMX_DEFER_SUMS=1 switches it on for experiments.
-    defer_row_sums = bool(_os.environ.get("PMX_DEFER_SUMS"))
+    # the second-stage row sums of the gradient reductions folded into the gradient gather (mappo._row_sums_deferred): eight small
+    # launches less on the chains of the 512-sample step.  (A first version ran them on a third stream beside the next backward kernel
+    # and LOST -- 1 380 against 1 995 steps/s: six fork / join pairs cost the captured graph more than the kernels cost the chain,
+    # tools/r03_iso2.sh.)  PMX_NO_DEFER_SUMS=1 restores a kernel per reduction.
+    defer_row_sums = not _os.environ.get("PMX_NO_DEFER_SUMS")
     overlap_allreduce = True   # data parallel: reduce the actor's gradient slice while the critic's backward runs
     graph_overlap_allreduce = False   # ... also in the hipGraph-replayed step (one graph per gradient group); see capture()
 
@@ -1132,32 +1135,41 @@ class PPOLearner:
                 if lo <= i < hi:
                     targets[i - lo] = v                  # the bfloat16 copy the library op multiplied by
         dev = self.bucket.grad.device
-        prev, _DEFER_ROW_SUMS[0] = _DEFER_ROW_SUMS[0], bool(self.defer_row_sums and dev.type == "cuda")
+        flat_ok = dev.type == "cuda" and all(t.dtype in (torch.float32, torch.bfloat16) for t in targets)     # (the gather below)
+        prev, _DEFER_ROW_SUMS[0] = _DEFER_ROW_SUMS[0], bool(self.defer_row_sums and flat_ok)
+        _PENDING_ROWS.clear()                                # (nothing of an earlier, failed call may match this one's addresses)
         root, unit = loss_root(loss)
         try:
             grads = torch.autograd.grad(root, targets, grad_outputs=unit, allow_unused=True, retain_graph=retain)
         finally:
             _DEFER_ROW_SUMS[0] = prev
-        if dev.type == "cuda":
-            join_row_sums(dev)                               # the deferred second-stage sums of the parameter gradients
         flat = [g.reshape(-1) if g is not None else torch.zeros(p.numel(), dtype=self.bucket.grad.dtype, device=dev)
                 for g, p in zip(grads, params)]
         first = sum(p.numel() for p in self.bucket.params[:lo])
+        if not (dev.type == "cuda" and all(g.dtype in (torch.float32, torch.bfloat16) for g in flat)):
+            flush_pending_rows()
         if dev.type == "cuda" and all(g.dtype in (torch.float32, torch.bfloat16) for g in flat):
             import ctypes as C
             from . import _lib
             lib = _lib.load()
             n = len(flat)
+            if any(not g.is_contiguous() for g in flat):
+                flush_pending_rows()                         # (a copy would read rows that have not been added yet)
             flat = [g.contiguous() for g in flat]
             src = (C.c_void_p * n)(*[g.data_ptr() for g in flat])
             isb = (C.c_uint8 * n)(*[1 if g.dtype == torch.bfloat16 else 0 for g in flat])
             cnt = (C.c_int32 * n)(*[g.numel() for g in flat])
+            # gradients that are still partial rows (mappo._row_sums_deferred): the gather adds them
+            pend = [pending_rows_of(g.data_ptr()) if g.dtype == torch.float32 else (0, 0) for g in flat]
+            rows = (C.c_int32 * n)(*[r for r, _ in pend])
+            stride = (C.c_int32 * n)(*[f for _, f in pend])
             offs, o = [], first
             for g in flat:
                 offs.append(o); o += g.numel()
             off = (C.c_int64 * n)(*offs)
             st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            _lib.check(lib.pmx_flatten_to_f32(n, src, isb, off, cnt, self.bucket.grad.data_ptr(), st), "pmx_flatten_to_f32")
+            _lib.check(lib.pmx_flatten_sum_to_f32(n, src, isb, rows, stride, off, cnt, self.bucket.grad.data_ptr(), st), "pmx_flatten_sum_to_f32")
+            _PENDING_ROWS.clear()
         else:
             total = sum(g.numel() for g in flat)
             torch.cat([g.to(self.bucket.grad.dtype) for g in flat], out=self.bucket.grad[first:first + total])
