@@ -209,8 +209,9 @@ def e2e_probe(layout, dev, rank, world, dist, n_envs, horizon, minibatch, use_gr
 
 NETWORK_NOTE = ("MAPPOAgent: actor tower = one fused HIP forward kernel + two backward kernels on bf16 MFMA (csrc/pmx_actor.hip; boards of 10, "
                 "11 and 28 position tiles = tiny, small and the 20x20 boards); critic batch-major / channels-last: MFMA attention, fused "
-                "in-projection, out-projection + LayerNorm and feed-forward + LayerNorm kernels (csrc/pmx_critic.hip, pmx_train.hip); heads and "
-                "the projector convolution on hipBLASLt / MIOpen")
+                "in-projection, out-projection + LayerNorm and feed-forward + LayerNorm kernels (csrc/pmx_critic.hip, pmx_train.hip), projector "
+                "conv + positional table and both heads' small ends as own kernels (pmx_actor.hip, pmx_heads.hip); the first linear of the "
+                "two heads on hipBLASLt")
 
 
 def _safe(fn, *a, **kw):
