@@ -751,6 +751,99 @@ def test_fused_clip_adam_ema_matches_the_torch_ops():
     assert all(abs(x - y) <= 1e-5 * y for x, y in zip(res[True][5], res[False][5]))
 
 
+def test_clip_adam_ema_tail_writes_the_bf16_copy_and_the_report_sums():
+    """pmx_clip_adam_ema_tail: the same update as pmx_clip_adam_ema (bit for bit), plus the parameters rounded to bfloat16 exactly as
+    torch rounds them, plus reports5 / the gradient norm added to the running sums."""
+    import ctypes as C
+    from pmx import _lib
+    lib = _lib.load()
+    n = 100_003
+    g0 = torch.Generator(device="cuda").manual_seed(5)
+    grad0, p0 = torch.randn(n, device="cuda", generator=g0) * 0.01, torch.randn(n, device="cuda", generator=g0)
+    m0, v0, e0 = torch.randn(n, device="cuda", generator=g0) * 0.01, torch.rand(n, device="cuda", generator=g0) * 1e-4, p0.clone()
+    reports = torch.tensor([0.5, -1.25, 2.0, 0.125, 3.0], device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = {}
+    for tail in (False, True):
+        grad, p, m, v, e = (t.clone() for t in (grad0, p0, m0, v0, e0))
+        scratch = torch.empty(_lib.OPT_PARTIALS, dtype=torch.float64, device="cuda")
+        norm = torch.zeros(1, device="cuda")
+        p16 = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+        sums = torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0, 6.0], device="cuda")
+        common = (grad.data_ptr(), p.data_ptr(), m.data_ptr(), v.data_ptr(), e.data_ptr(), n, scratch.data_ptr(), None, 3e-4, 1.0, 0.9, 0.999,
+                  1e-8, 0.5, 0.999, norm.data_ptr())
+        if tail:
+            rc = lib.pmx_clip_adam_ema_tail(*common, p16.data_ptr(), reports.data_ptr(), sums.data_ptr(), st)
+        else:
+            rc = lib.pmx_clip_adam_ema(*common, st)
+        assert rc == 0
+        out[tail] = (grad, p, m, v, e, norm.clone(), p16, sums)
+    for a, b in zip(out[True][:6], out[False][:6]):
+        assert torch.equal(a, b)
+    assert torch.equal(out[True][6], out[True][1].to(torch.bfloat16))
+    want = torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0, 6.0], device="cuda") + torch.cat([reports, out[True][5]])
+    assert torch.allclose(out[True][7], want, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("rows", [1, 7, 64, 301])
+def test_flatten_sum_adds_partial_rows_while_it_gathers(rows):
+    """pmx_flatten_sum_to_f32: tensors that are still partial rows (row 0 of a buffer = where the sum would go, rows 1 .. n behind
+    it) arrive summed, ordinary float32 / bfloat16 tensors are copied / widened, all in one launch."""
+    import ctypes as C
+    from pmx import _lib
+    lib = _lib.load()
+    torch.manual_seed(rows)
+    floats = 1120
+    buf = torch.randn((1 + rows) * floats, device="cuda")                      # row 0: garbage the gather must not read
+    plain = torch.randn(333, device="cuda")
+    half = torch.randn(77, device="cuda").to(torch.bfloat16)
+    views = [buf[:1024], buf[1024:1056], plain, buf[1056:1120], half]           # three slices of row 0 among ordinary tensors
+    n = len(views)
+    offs, o = [], 0
+    for t in views:
+        offs.append(o); o += t.numel()
+    dst = torch.full((o,), float("nan"), device="cuda")
+    in_buf = [t.data_ptr() >= buf.data_ptr() and t.data_ptr() < buf.data_ptr() + 4 * floats and t.dtype == torch.float32 for t in views]
+    rc = lib.pmx_flatten_sum_to_f32(n, (C.c_void_p * n)(*[t.data_ptr() for t in views]), (C.c_uint8 * n)(*[1 if t.dtype == torch.bfloat16 else 0 for t in views]),
+                                    (C.c_int32 * n)(*[rows if f else 0 for f in in_buf]), (C.c_int32 * n)(*[floats if f else 0 for f in in_buf]),
+                                    (C.c_int64 * n)(*offs), (C.c_int32 * n)(*[t.numel() for t in views]), dst.data_ptr(),
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    summed = buf.view(1 + rows, floats)[1:].double().sum(0)
+    ref = torch.cat([summed[:1024], summed[1024:1056], plain.double(), summed[1056:1120], half.double()])
+    assert float((dst.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert torch.equal(dst[offs[2]:offs[2] + 333], plain) and torch.equal(dst[offs[4]:], half.float())
+
+
+def test_learner_gradient_with_and_without_the_folded_row_sums_and_the_unit_root():
+    """The learner's gradient path (the fused objective differentiated as a 5-vector against the constant unit gradient, second-stage
+    row sums folded into the gather) against the plain one (loss.backward() semantics: `torch.autograd.grad(loss, ...)`, a kernel per
+    reduction): same gradients up to the order of the float32 row sums and of the tower's LDS adds."""
+    from pmx import mappo
+    H, W, B = 11, 14, 256
+    torch.manual_seed(4)
+    obs = (torch.rand(B, 8, H, W, device="cuda") < 0.2).to(torch.uint8)
+    merged = (torch.rand(B // 2, 8, H, W, device="cuda") < 0.2).to(torch.uint8)
+    act = torch.randint(0, 5, (B,), device="cuda")
+    old_logp, adv, ret = -torch.rand(B, device="cuda") - 1, torch.randn(B, device="cuda"), torch.randn(B, device="cuda")
+    torch.manual_seed(9)
+    m = mappo.MAPPOAgent((8, H, W)).cuda()
+    L = mappo.PPOLearner(m, autocast_dtype=torch.bfloat16)
+    grads = {}
+    for folded in (True, False):
+        L.defer_row_sums = folded
+        with L._shadow_context(), torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            loss, _ = mappo.ppo_loss(m, obs, merged, act, old_logp, adv, ret, 0.2, 0.01)
+        if not folded:
+            del loss._pmx_stats                          # -> loss_root() hands back the loss itself: the select and the scalings run
+        L.bucket.grad.zero_()
+        L._backward_into_bucket(loss)
+        grads[folded] = L.bucket.grad.clone()
+        assert not mappo._PENDING_ROWS
+    rel = float((grads[True] - grads[False]).norm() / grads[False].norm())
+    assert 0.0 < float(grads[False].norm()) and rel <= 2e-3, rel
+
+
 def test_bf16_shadow_weights_give_the_autocast_step():
     """The optimizer step with the library-op parameters read from the bfloat16 copy of the bucket (PPOLearner.shadow_weights)
     against the plain autocast step: autocast rounds the same float32 weights to the same bfloat16 values per use, so the
