@@ -9,7 +9,7 @@ mkdir -p $ROOT/ab
 OBJ=$ROOT/ab/$NAME.${SRC%.hip}.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off "$@" -c csrc/$SRC -o $OBJ -Rpass-analysis=kernel-resource-usage 2>&1 | grep -c "error" || true
 OBJS=""
-for o in pmx_step pmx_api pmx_train pmx_actor pmx_critic; do
+for o in pmx_step pmx_api pmx_train pmx_actor pmx_critic pmx_heads; do
   if [ "$o.hip" == "$SRC" ]; then OBJS="$OBJS $OBJ"; else OBJS="$OBJS build/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared $OBJS build/pmx_stamp.cpp -o $ROOT/ab/$NAME.so
