@@ -144,7 +144,7 @@ def emit_team_probe(lay, n_envs, length, dev, rank, actions, launches=ROOFLINE_M
                     "(VecMAPPOTrainer.rollout), one launch per tick"}
 
 
-def e2e_probe(layout, dev, rank, world, dist, n_envs, horizon, minibatch, use_graph, algorithm="mappo", rehearse_dp=False):
+def e2e_probe(layout, dev, rank, world, dist, n_envs, horizon, minibatch, use_graph, algorithm="mappo", rehearse_dp=False, autocast=True):
     """One full MAPPO update -- rollout of `horizon` ticks of `n_envs` envs with policy inference, GAE, UPDATE_EPOCHS epochs of
     `minibatch`-sample optimizer steps -- timed end to end after a short warm-up (pacman_mappo_resnet.py:461-600).  With more
     than one rank every optimizer step all-reduces the flat fp32 gradient bucket over RCCL, the actor's slice while the
@@ -155,7 +155,7 @@ def e2e_probe(layout, dev, rank, world, dist, n_envs, horizon, minibatch, use_gr
     dp = dist is not None and (world > 1 or rehearse_dp)
     tr = trainer.VecMAPPOTrainer(layout, n_envs, horizon=horizon, minibatch=minibatch, device=dev, opponent="random", rank=rank,
                                  world_size=world, process_group=dist.group.WORLD if dp else None, use_graph=use_graph,
-                                 algorithm=algorithm, force_collectives=dp and world == 1)
+                                 algorithm=algorithm, force_collectives=dp and world == 1, use_autocast=autocast)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -222,7 +222,7 @@ def _safe(fn, *a, **kw):
 
 
 def ppo_probe(layname, layout, dev, rank=0, world=1, dist=None, n_envs=16384, horizon=32, large_minibatch=16384, rehearsal_dist=None,
-              algorithms=("mappo",)):
+              algorithms=("mappo",), float32_too=False):
     """The second half of BASELINE.json's metric: end-to-end MAPPO (rollout with policy inference + GAE + 3 PPO epochs) on the
     workload, once at the reference's minibatch of 512 samples per GPU (pacman_mappo_resnet.py:18; replayed from hipGraphs, where
     the step is launch-bound) and once at a large minibatch (fewer, larger optimizer steps -- a different optimisation schedule
@@ -236,6 +236,12 @@ def ppo_probe(layname, layout, dev, rank=0, world=1, dist=None, n_envs=16384, ho
     for alg in algorithms:
         if alg != "mappo":
             other[alg] = _safe(e2e_probe, layout, dev, rank, world, dist, n_envs, horizon, large_minibatch, False, algorithm=alg)
+    if world == 1 and float32_too:
+        # the reference's own arithmetic (float32 planes, float32 network on the library ops: no hand-written network kernel runs), on a
+        # quarter of the envs to bound the run: what the bf16 figures above are a speed-up OVER, on the same GPU
+        f32 = _safe(e2e_probe, layout, dev, rank, world, dist, max(n_envs // 4, 512), horizon, large_minibatch, False, autocast=False)
+        f32["note"] = "float32 planes and network (torch library ops), no autocast; a quarter of the envs of the bf16 rows"
+        other["float32_end_to_end"] = f32
     ref, big = runs
     out = {"config": f"{layname}, {n_envs} envs/GPU, horizon {horizon}, 3 epochs, paired minibatches (the centralised critic runs once "
                      "per env-tick pair), bf16 autocast, byte observation planes, in-kernel randomTeam opponent",
@@ -499,7 +505,7 @@ def main():
         if layname == "mazeGenerator" or layname == "bloxCapture":
             ppo = ppo_probe(layname, lay, dev, rank, world, dist, n_envs=n_envs, rehearsal_dist=None, algorithms=("mappo", "ippo"))
         else:
-            ppo = ppo_probe(layname, lay, dev, rank, world, dist, rehearsal_dist=rehearsal_dist)
+            ppo = ppo_probe(layname, lay, dev, rank, world, dist, rehearsal_dist=rehearsal_dist, float32_too=True)
             if not args.no_config5:
                 cfg5 = config5_probe(dev, rank, world, dist)
         if rehearsal_dist is not None and dist is None:
