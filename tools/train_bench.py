@@ -22,6 +22,7 @@ ap.add_argument("--obs", default=None, help="observation planes (default: the tr
 ap.add_argument("--algorithm", default="mappo", choices=["mappo", "ippo"])
 ap.add_argument("--opponent", default="random")
 ap.add_argument("--no-autocast", action="store_true")
+ap.add_argument("--graph", action="store_true", help="replay the optimizer step from a hipGraph (what bench.py does at 512 samples)")
 args = ap.parse_args()
 
 import pmx
@@ -31,7 +32,7 @@ layout = args.layout
 if layout == "mazes":       # one generated 20x20 maze per env (BASELINE config 5)
     layout = [pmx.Layout.from_text(pmx.maze_generator.generate_maze(s)) for s in range(1, args.envs + 1)]
 tr = trainer.VecMAPPOTrainer(layout, args.envs, algorithm=args.algorithm, horizon=args.horizon, minibatch=args.minibatch, epochs=args.epochs,
-                             obs_dtype=args.obs, opponent=args.opponent, use_autocast=not args.no_autocast)
+                             obs_dtype=args.obs, opponent=args.opponent, use_autocast=not args.no_autocast, use_graph=args.graph)
 sync = lambda: torch.cuda.synchronize()
 tr.rollout(); tr.compute_gae(); sync()          # warm-up (MIOpen find, allocator)
 res = []
