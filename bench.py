@@ -214,7 +214,14 @@ NETWORK_NOTE = ("MAPPOAgent: actor tower = one fused HIP forward kernel + two ba
                 "two heads on hipBLASLt")
 
 
+def _progress(msg):
+    """Stage marks on stderr (rank 0): a run that takes minutes must not look hung, and a stage that IS hung must be nameable."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"bench: {msg} [{time.strftime('%H:%M:%S')}]", file=sys.stderr, flush=True)
+
+
 def _safe(fn, *a, **kw):
+    _progress(f"{fn.__name__} minibatch {a[7] if len(a) > 7 else '-'} " + " ".join(f"{k}={v}" for k, v in kw.items()))
     try:
         return fn(*a, **kw)
     except Exception as e:                      # a probe must not lose the bench line
@@ -288,10 +295,18 @@ def main():
     ap.add_argument("--no-dp-rehearsal", action="store_true", help="skip the one-rank RCCL rehearsal of the data-parallel optimizer step")
     ap.add_argument("--no-emit", action="store_true", help="skip the pmx_emit_team_obs (training-loop observation kernel) pass")
     ap.add_argument("--no-config5", action="store_true", help="skip the 20x20 generated-maze MAPPO / IPPO probe of the default run")
+    ap.add_argument("--float32-e2e", action="store_true",
+                    help="add the float32 / library-op end-to-end figure (ppo.float32_end_to_end); not in the default run: MIOpen's "
+                         "solver search for the float32 convolutions can take minutes on a fresh box")
     ap.add_argument("--fixed-sweep", action="store_true",
                     help="run EVERY pass with the sweep direction fixed (all bytes to HBM): for profiler runs, so that the trace's average "
                          "duration of the expansion kernel is the one `roofline` is quoted on")
     args = ap.parse_args()
+    # stdout carries exactly ONE line, the JSON: whatever libraries print on file descriptor 1 meanwhile (RCCL's version banner at
+    # communicator creation, MIOpen's notes) goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -432,6 +447,7 @@ def main():
     # reference-dtype parity path and is not launched by the trainer at all
     emit = None
     if not args.no_emit:
+        _progress("emit_team_probe")
         emit = emit_team_probe(lay, n_envs, length, dev, rank, actions)
         try:
             if n_envs == WORKLOADS[args.workload][1]:
@@ -484,6 +500,7 @@ def main():
         if emit is not None:
             line["roofline_emit_team"] = emit
         if not args.no_cpu_baseline and world == 1:
+            _progress("cpu_baseline")
             line["cpu_baseline"] = cpu_baseline(lay[0].text if isinstance(lay, list) else lay.text, length, layname=layname)
     env.close()
     ppo = cfg5 = None
@@ -505,7 +522,7 @@ def main():
         if layname == "mazeGenerator" or layname == "bloxCapture":
             ppo = ppo_probe(layname, lay, dev, rank, world, dist, n_envs=n_envs, rehearsal_dist=None, algorithms=("mappo", "ippo"))
         else:
-            ppo = ppo_probe(layname, lay, dev, rank, world, dist, rehearsal_dist=rehearsal_dist, float32_too=True)
+            ppo = ppo_probe(layname, lay, dev, rank, world, dist, rehearsal_dist=rehearsal_dist, float32_too=args.float32_e2e)
             if not args.no_config5:
                 cfg5 = config5_probe(dev, rank, world, dist)
         if rehearsal_dist is not None and dist is None:
@@ -515,7 +532,7 @@ def main():
             line["ppo"] = ppo
         if cfg5 is not None:
             line["ppo_config5"] = cfg5
-        print(json.dumps(line))
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())           # the ONE line of stdout
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
