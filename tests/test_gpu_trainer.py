@@ -362,6 +362,34 @@ def test_mfma_attention_forward_with_large_and_shifted_scores(amp, shift, far):
     assert float(((lse - torch.logsumexp(sc, -1)).abs() / (1.0 + torch.logsumexp(sc, -1).abs())).max()) <= 2e-3
 
 
+@pytest.mark.parametrize("S", [154, 400])
+def test_mfma_attention_forward_rows_one_key_dominates(S):
+    """Rows whose probability mass sits on ONE key (score gap ~20 nats), at magnitudes where the kernel exponentiates against the
+    head's norm bound rather than the row maximum: no probability is exactly 1 there, so the log-sum-exp must come from the
+    unrounded probabilities (a bf16-rounded dominant term would be off by up to 2^-9 = 2e-3 relative, i.e. in the log) and the output
+    must still be the dominant key's value row."""
+    from pmx import mappo
+    torch.manual_seed(5)
+    B = 4
+    x = torch.randn(S, B, 96, device="cuda") * 0.3
+    tgt = torch.randint(0, 8, (S,), device="cuda")                  # query i looks at key tgt[i], one of the first eight
+    code = torch.eye(8, device="cuda") * 8.5                        # those keys carry orthogonal codes, the others only noise
+    for h in range(4):
+        x[:8, :, 32 + 8 * h:40 + 8 * h] += code[:, None, :]
+        x[:, :, 8 * h:8 * h + 8] += code[tgt][:, None, :]             # queries carry their target's code
+    qkv = x.to(torch.bfloat16)
+    out, lse = mappo.attention8_forward(qkv, want_lse=True)
+    q, k, v = qkv.float().chunk(3, dim=-1)
+    q, k, v = (t.reshape(S, B, 4, 8).permute(1, 2, 0, 3) for t in (q, k, v))
+    sc = torch.matmul(q.double(), k.double().transpose(-1, -2)) / 8 ** 0.5
+    top2 = sc.topk(2, dim=-1).values
+    assert float((top2[..., 0] - top2[..., 1]).median()) > 8.0           # most rows are dominated by one key
+    ref_lse = torch.logsumexp(sc, -1)
+    assert float((lse.double() - ref_lse).abs().max()) <= 5e-4, float((lse.double() - ref_lse).abs().max())
+    ref = torch.matmul(torch.softmax(sc, -1), v.double()).permute(2, 0, 1, 3).reshape(S, B, 32)
+    assert float((out.double() - ref).abs().max()) <= 2e-2 * (float(ref.abs().max()) + 1e-6)
+
+
 @pytest.mark.parametrize("S,B", [(154, 19), (140, 5), (400, 4), (33, 3), (640, 2), (397, 3)])
 def test_mfma_attention_backward_matches_torch(S, B):
     """pmx_attn8_backward against torch autograd of softmax(q k^T / sqrt(8)) v in float32 on the same bf16 inputs."""
