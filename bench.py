@@ -235,7 +235,9 @@ def ppo_probe(layname, layout, dev, rank=0, world=1, dist=None, n_envs=16384, ho
     the step is launch-bound) and once at a large minibatch (fewer, larger optimizer steps -- a different optimisation schedule
     than the reference's, stated as such).  On one GPU the data-parallel step is rehearsed as well (one-rank RCCL group)."""
     runs, rehearsal, other = [], [], {}
-    for mb, graph in ((512, True), (large_minibatch, False)):
+    # one GPU: both steps are replayed from a hipGraph (at 16 384 samples that is worth 2.6 % on smallCapture and nothing on the 20 x 20
+    # boards: the step is GPU-bound); data parallel, the large step stays eager -- its two slice all-reduces overlap the backward
+    for mb, graph in ((512, True), (large_minibatch, world == 1)):
         runs.append(_safe(e2e_probe, layout, dev, rank, world, dist, n_envs, horizon, mb, graph))
     if world == 1 and rehearsal_dist is not None:
         for mb, graph in ((512, True), (large_minibatch, False)):
