@@ -524,7 +524,8 @@ def main():
         if layname == "mazeGenerator" or layname == "bloxCapture":
             ppo = ppo_probe(layname, lay, dev, rank, world, dist, n_envs=n_envs, rehearsal_dist=None, algorithms=("mappo", "ippo"))
         else:
-            ppo = ppo_probe(layname, lay, dev, rank, world, dist, rehearsal_dist=rehearsal_dist, float32_too=args.float32_e2e)
+            ppo = ppo_probe(layname, lay, dev, rank, world, dist, n_envs=n_envs, rehearsal_dist=rehearsal_dist,
+                            float32_too=args.float32_e2e)
             if not args.no_config5:
                 cfg5 = config5_probe(dev, rank, world, dist)
         if rehearsal_dist is not None and dist is None:

@@ -1459,10 +1459,19 @@ class PPOLearner:
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
         state.clear()
+        # Capture in THREAD-LOCAL error mode: in the default (global) mode a capture in progress forbids "unsafe" runtime calls from
+        # every thread of the process -- and ProcessGroupNCCL's watchdog thread polls the events of recent collectives with
+        # hipEventQuery, which then fails with hipErrorStreamCaptureUnsupported and takes the process down (seen when a capture began
+        # right behind the warm-up steps' all-reduces).  This thread makes no such call while it captures; other threads' launches on
+        # the capturing streams (autograd's workers) are recorded either way.  The pause lets the watchdog retire what has completed.
+        if self.dp:
+            import time as _time
+            _time.sleep(0.25)
+        tl = dict(capture_error_mode="thread_local")
         if not segmented:
             self._graph = torch.cuda.CUDAGraph()
             self._graphs = None
-            with torch.cuda.graph(self._graph):
+            with torch.cuda.graph(self._graph, **tl):
                 seg_first()
                 for k in range(1, len(groups)):
                     seg_group(k)
@@ -1471,7 +1480,7 @@ class PPOLearner:
             self._graphs, pool = [], None
             for k in range(len(groups) + 1):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
+                with torch.cuda.graph(g, pool=pool, **tl):
                     if k == 0:
                         seg_first()
                     elif k < len(groups):
