@@ -715,19 +715,22 @@ def test_fused_ppo_loss_is_what_ppo_loss_uses_and_agrees_with_the_torch_path():
 def test_one_launch_minibatch_gather_equals_torch_indexing():
     """The replayed optimizer step fed by pmx_gather_rows (paired minibatches, reports summed inside the graph) against the
     same replay fed by torch indexing and copies: same random streams, so weights, EMA and the averaged reports agree (not bit
-    for bit: the tower's data-gradient kernel adds its per-channel sums with LDS float adds, whose order differs from run to run)."""
+    for bit: the tower's data-gradient kernel adds its per-channel sums with LDS float adds, whose order differs from run to run).
+    FOUR optimizer steps, not the whole update: over a whole update (24 steps here) that 1e-7 noise decides, now and then, on which
+    side of the clip threshold a borderline sample falls, and two runs of the SAME path then differ by a few 1e-4 in the weights and
+    ~0.05 in the averaged gradient norm (tools/r03_flaky.sh) -- a property of PPO's clipping, not of either feeding path."""
     from pmx import trainer
     res = {}
     for gather in (True, False):
         tr = trainer.VecMAPPOTrainer("tinyCapture", 64, horizon=8, minibatch=128, opponent="random", use_graph=True, seed=11)
         tr.graph_gather = gather
-        tr.rollout(); tr.compute_gae(); tr.update()
+        tr.rollout(); tr.compute_gae(); tr.update(max_steps=4)
         res[gather] = (tr.learner.bucket.data.clone(), tr.learner.ema.clone(), {k: float(v) for k, v in tr.stats.items() if k in ("pg", "vl", "entropy", "loss", "grad_norm")})
         tr.env.close()
     for a, b in ((res[True][0], res[False][0]), (res[True][1], res[False][1])):
-        assert float((a - b).norm()) <= 2e-3 * float(b.norm()), float((a - b).norm() / b.norm())
+        assert float((a - b).norm()) <= 2e-5 * float(b.norm()), float((a - b).norm() / b.norm())      # (measured: <= 2e-7)
     for k in res[True][2]:
-        assert abs(res[True][2][k] - res[False][2][k]) <= 2e-2 * (abs(res[False][2][k]) + 1e-2), (k, res[True][2][k], res[False][2][k])
+        assert abs(res[True][2][k] - res[False][2][k]) <= 1e-3 * (abs(res[False][2][k]) + 1e-2), (k, res[True][2][k], res[False][2][k])
 
 
 def test_gather_rows_matches_index_select():
