@@ -287,6 +287,11 @@ int pmx_ppo_loss(const void *logits_dev, int32_t logits_bf16, const float *value
  * pacman_mappo_resnet.py:560-569 does with `batch_indices` on its CPU tensors.) */
 int pmx_gather_rows(int32_t n, const void *const *src_dev, void *const *dst_dev, const int64_t *const *idx_dev,
                     const int32_t *row_bytes, const int32_t *rows_per_index, const int64_t *n_rows, void *stream);
+/* The same launch also writes n_values <= 8 float32 host values to consecutive device words (pmx_set_floats folded in: the scalars a
+ * replayed graph reads travel with the minibatch). */
+int pmx_gather_rows_set_floats(int32_t n, const void *const *src_dev, void *const *dst_dev, const int64_t *const *idx_dev,
+                               const int32_t *row_bytes, const int32_t *rows_per_index, const int64_t *n_rows, float *floats_dst_dev,
+                               const float *values, int32_t n_values, void *stream);
 /* n <= 8 float32 host values to consecutive device words, passed as kernel arguments (the scalars a replayed hipGraph reads). */
 int pmx_set_floats(float *dst_dev, const float *values, int32_t n, void *stream);
 

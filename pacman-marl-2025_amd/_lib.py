@@ -98,6 +98,7 @@ PROTOTYPES = [
     ("pmx_flatten_to_f32", C.c_int, [_I32, _VP, _VP, _VP, _VP, _VP, _VP]),
     ("pmx_flatten_sum_to_f32", C.c_int, [_I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     ("pmx_gather_rows", C.c_int, [_I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    ("pmx_gather_rows_set_floats", C.c_int, [_I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _VP]),
     ("pmx_set_floats", C.c_int, [_VP, _VP, _I32, _VP]),
     ("pmx_attn8_forward_layout", C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP]),
     ("pmx_attn8_backward_layout", C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),

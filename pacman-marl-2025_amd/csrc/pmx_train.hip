@@ -1819,10 +1819,14 @@ struct PmxGatherArgs {
     const int64_t *idx[8];
     int32_t row_bytes[8], rows_per_index[8];
     int64_t n_rows[8];
+    float *floats_dst;                  // optional: up to 8 scalars written by the same launch (pmx_gather_rows_set_floats)
+    float floats[8];
+    int32_t n_floats;
 };
 __global__ __launch_bounds__(256) void pmx_gather_rows_kernel(PmxGatherArgs a)
 {
     const int t = blockIdx.y;
+    if (blockIdx.x == 0 && t == 0 && (int)threadIdx.x < a.n_floats) a.floats_dst[threadIdx.x] = a.floats[threadIdx.x];
     const int rb = a.row_bytes[t], m = a.rows_per_index[t];
     const char *src = a.src[t];
     char *dst = a.dst[t];
@@ -1851,9 +1855,19 @@ __global__ __launch_bounds__(256) void pmx_gather_rows_kernel(PmxGatherArgs a)
 extern "C" int pmx_gather_rows(int32_t n, const void *const *src_dev, void *const *dst_dev, const int64_t *const *idx_dev,
                                const int32_t *row_bytes, const int32_t *rows_per_index, const int64_t *n_rows, void *stream)
 {
+    return pmx_gather_rows_set_floats(n, src_dev, dst_dev, idx_dev, row_bytes, rows_per_index, n_rows, nullptr, nullptr, 0, stream);
+}
+extern "C" int pmx_gather_rows_set_floats(int32_t n, const void *const *src_dev, void *const *dst_dev, const int64_t *const *idx_dev,
+                                          const int32_t *row_bytes, const int32_t *rows_per_index, const int64_t *n_rows,
+                                          float *floats_dst_dev, const float *values, int32_t n_values, void *stream)
+{
     if (n < 1 || n > 8 || !src_dev || !dst_dev || !idx_dev || !row_bytes || !rows_per_index || !n_rows) return PMX_ERR_INVALID;
+    if (n_values < 0 || n_values > 8 || (n_values > 0 && (!floats_dst_dev || !values))) return PMX_ERR_INVALID;
     PmxGatherArgs a;
     memset(&a, 0, sizeof(a));
+    a.floats_dst = floats_dst_dev;
+    a.n_floats = n_values;
+    for (int i = 0; i < n_values; ++i) a.floats[i] = values[i];
     int64_t most = 0;
     for (int t = 0; t < n; ++t) {
         if (!src_dev[t] || !dst_dev[t] || !idx_dev[t] || row_bytes[t] < 4 || (row_bytes[t] & 3) || rows_per_index[t] < 1 || n_rows[t] < 0)
@@ -1864,8 +1878,9 @@ extern "C" int pmx_gather_rows(int32_t n, const void *const *src_dev, void *cons
         const int64_t units = n_rows[t] * (row_bytes[t] >> ((row_bytes[t] & 15) == 0 ? 4 : 2));
         most = units > most ? units : most;
     }
-    if (most == 0) return PMX_OK;
+    if (most == 0 && n_values == 0) return PMX_OK;
     int64_t blocks = (most + 255) / 256;
+    if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(pmx_gather_rows_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? PMX_OK : PMX_ERR_HIP;

@@ -1511,10 +1511,13 @@ class PPOLearner:
             fin()
         self._graphs[-1].replay()
 
-    def _set_graph_scalars(self, clip_eps, ent_coef, step):
+    def _graph_scalar_values(self, clip_eps, ent_coef, step):
         b1, b2 = self.betas
         bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
-        vals = (self.lr / bc1, 1.0 / math.sqrt(bc2), clip_eps, ent_coef)
+        return tuple(float(v) for v in (self.lr / bc1, 1.0 / math.sqrt(bc2), clip_eps, ent_coef))
+
+    def _set_graph_scalars(self, clip_eps, ent_coef, step):
+        vals = self._graph_scalar_values(clip_eps, ent_coef, step)
         if self._g_sc.is_cuda:
             # the four values travel as kernel arguments of ONE launch: stream-ordered, no host staging buffer that could be
             # recycled while a copy is still in flight
@@ -1559,9 +1562,10 @@ class PPOLearner:
             assert index.numel() * rows_per_index[name] == d_t.shape[0], (name, index.numel(), d_t.shape)
         assert index.dtype == torch.int64 and index.is_contiguous()
         st = C.c_void_p(torch.cuda.current_stream(index.device).cuda_stream)
-        _lib.check(lib.pmx_gather_rows(n, src, dst, idx, rb, m, nr, st), "pmx_gather_rows")
         self.step_count += 1
-        self._set_graph_scalars(clip_eps, ent_coef, self.step_count)
+        vals = self._graph_scalar_values(clip_eps, ent_coef, self.step_count)        # (they travel with the gather: one launch)
+        arr = (C.c_float * 4)(*vals)
+        _lib.check(lib.pmx_gather_rows_set_floats(n, src, dst, idx, rb, m, nr, self._g_sc.data_ptr(), arr, 4, st), "pmx_gather_rows_set_floats")
         self._replay()
         return self._g_stats
 

@@ -750,6 +750,15 @@ def test_gather_rows_matches_index_select():
     assert rc == 0
     rows = torch.stack((2 * idx, 2 * idx + 1), 1).reshape(-1)
     assert torch.equal(dst_a, src_a[rows]) and torch.equal(dst_b, src_b[idx])
+    # the same launch carrying the scalars a replayed graph reads
+    dst_a.zero_(); dst_b.zero_()
+    sc = torch.full((6,), -1.0, device="cuda")
+    rc = lib.pmx_gather_rows_set_floats(n, VP(src_a.data_ptr(), src_b.data_ptr()), VP(dst_a.data_ptr(), dst_b.data_ptr()), VP(idx.data_ptr(), idx.data_ptr()),
+                                        I32(1120, 4), I32(2, 1), I64(200, 100), sc.data_ptr(), (C.c_float * 4)(0.25, 1.5, -3.0, 7.0), 4,
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    assert torch.equal(dst_a, src_a[rows]) and torch.equal(dst_b, src_b[idx])
+    assert sc.tolist() == [0.25, 1.5, -3.0, 7.0, -1.0, -1.0]
 
 
 def test_fused_clip_adam_ema_matches_the_torch_ops():
