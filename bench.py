@@ -194,7 +194,8 @@ def e2e_probe(layout, dev, rank, world, dist, n_envs, horizon, minibatch, use_gr
     del tr
     torch.cuda.empty_cache()
     env_steps = n_envs * horizon * world
-    return {"end_to_end_env_steps_per_s": env_steps / (t_roll + t_upd), "algorithm": algorithm, "minibatch_per_gpu": minibatch,
+    return {"end_to_end_env_steps_per_s": env_steps / (t_roll + t_upd), "ppo_updates_per_s": 1.0 / (t_roll + t_upd),
+            "algorithm": algorithm, "minibatch_per_gpu": minibatch,
             "envs_per_gpu": n_envs, "horizon": horizon, "epochs": 3, "optimizer_steps": steps, "rollout_s": t_roll,
             "gae_plus_update_s": t_upd, "rollout_env_steps_per_s": env_steps / t_roll, "optimizer_steps_per_s": steps / t_upd,
             "train_samples_per_s": steps * minibatch * world / t_upd, "hipgraph_replay": bool(graphs), "hipgraphs_per_step": graphs,
@@ -258,6 +259,8 @@ def ppo_probe(layname, layout, dev, rank=0, world=1, dist=None, n_envs=16384, ho
            "end_to_end_env_steps_per_s": big.get("end_to_end_env_steps_per_s"), "end_to_end_minibatch": large_minibatch,
            "end_to_end_env_steps_per_s_mb512": ref.get("end_to_end_env_steps_per_s"),
            "optimizer_steps_per_s": ref.get("optimizer_steps_per_s"), "samples_per_gpu_per_step": 512,
+           # BASELINE.json's "PPO updates/s": one update = the rollout of n_envs x horizon env-ticks + GAE + 3 epochs over it
+           "ppo_updates_per_s": big.get("ppo_updates_per_s"), "ppo_updates_per_s_mb512": ref.get("ppo_updates_per_s"),
            "rollout_env_steps_per_s": big.get("rollout_env_steps_per_s"),
            "network": NETWORK_NOTE,
            "reference_cpu": "0.49 s per optimizer step (2 steps/s) and about 80 env-steps/s end to end on 8 host cores, smallCapture; 1.24 s "
