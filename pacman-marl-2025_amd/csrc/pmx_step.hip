@@ -1138,17 +1138,27 @@ __global__ __launch_bounds__(PMX_BLOCK) void pmx_expand4_kernel(PmxExpandParams 
 // Training-side emission: what the MAPPO rollout does with every tick's observations (pacman_mappo_resnet.py:462-469),
 // straight from the snapshots: the two learners' planes -- canonicalised for a red team (canonicalize_obs :215-229: x
 // flipped, capsule planes 2 <-> 3 and food planes 6 <-> 7 swapped) -- and merge_obs_for_critic (:267-274: the first
-// learner's planes with plane 4 cleared and plane 1 = max of both learners' self planes).  One wavefront per (env, slot),
-// slots 0, 1 = the learners, slot 2 = the merged input; same packed-bit-stream construction and look-up-table expansion
-// as pmx_expand_kernel, with the flip applied while the stream is built (rows bit-reversed, x -> W-1-x).
+// learner's planes with plane 4 cleared and plane 1 = max of both learners' self planes).  Slots 0, 1 = the learners,
+// slot 2 = the merged input; same packed-bit-stream construction and look-up-table expansion as pmx_expand_kernel, with
+// the flip applied while the stream is built (rows bit-reversed, x -> W-1-x).
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t flip_row(uint32_t v, int W, bool flip) { return flip ? (__builtin_bitreverse32(v) >> (32 - W)) : v; }
 
+// One wavefront per ENV.  The two learners' streams are assembled side by side, one per half of the wave (lanes 0-31: the
+// first learner's snapshot, lanes 32-63: the second's; H <= 32 rows each), and the merged slot is the first learner's
+// stream patched in registers while it is expanded (the ally bit of plane 4 cleared, the mate's bit of plane 1 set), so no
+// third stream is built.  The 16-byte vectors of all slots are then dealt to the lanes as ONE index range (2 or 3 x n_vec):
+// on smallCapture 231 vectors fill four store instructions to 90 % where one wave per (env, slot) -- the round-2 kernel --
+// filled six to 60 %, and the set-up (snapshot loads, stream assembly, the block's look-up table) is paid once per env
+// instead of once per slot: 28.3 -> 14.5 us at 16 384 smallCapture envs, 12.3 -> 10.0 / 20.3 -> 17.0 us on the 20 x 20 boards
+// (4 096 / 8 192 envs).  U = store instructions per group of look-ups (1: 16.0 us, 2: 14.5, 4: 14.4, 5: 15.0 on smallCapture).
 template <int DT>
 __global__ __launch_bounds__(PMX_BLOCK) void pmx_emit_team_kernel(PmxEmitParams p)
 {
     constexpr int VEC = ObsVec<DT>::VEC;
-    __shared__ uint32_t tab[4][8 * 32 * 32 / 32 + 8];
+    constexpr int U = 2;
+    constexpr int TW = 8 * 32 * 32 / 32 + 8;
+    __shared__ uint32_t tab[4][2][TW];                        // [wave][learner][stream words]
     __shared__ __align__(16) uint32_t lut[DT == 0 ? 16 * 4 : (DT == 1 ? 256 * 4 : 256 * 2)];
     {
         const uint32_t i = threadIdx.x;
@@ -1164,52 +1174,48 @@ __global__ __launch_bounds__(PMX_BLOCK) void pmx_emit_team_kernel(PmxEmitParams 
     }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    const int half = lane >> 5, hl = lane & 31;
     const int W = p.lay_W, H = p.lay_H, HW = H * W;
-    const int n_slots = p.merged ? 3 : 2;
-    const long q = (long)blockIdx.x * 4 + wave;
-    if (q >= (long)p.N * n_slots) return;
-    const long env = q / n_slots;
-    const int slot = (int)(q - env * n_slots);
-    const bool flip = p.red != 0, merged = slot == 2;
+    long blk = (long)blockIdx.x;
+    if ((p.N & 127) == 0) {                                   // the 16 envs of one 64-byte line of snapshot words: one XCD
+        const long r = blk & 31;
+        blk = (blk & ~31L) + (r & 7) * 4 + (r >> 3);
+    }
+    const long env = blk * 4 + wave;
+    if (env >= p.N) return;
+    const bool flip = p.red != 0;
     const int first = p.red ? 0 : 1, second = first + 2;
-    const int agent = slot == 1 ? second : first;             // the merged input is built on the first learner's planes
+    const int agent = half ? second : first;
     const size_t N = (size_t)p.N;
-    const uint32_t *S = p.snap[agent] + env;
-    uint32_t *T = tab[wave];
+    const uint32_t *S = (half ? p.snap[second] : p.snap[first]) + env;
+    uint32_t *T = tab[wave][half];
     const PmxLayoutDev *L = p.lay + (p.layout_idx ? p.layout_idx[env] : 0);
 
-    const uint32_t food = lane < H ? S[(size_t)lane * N] : 0u;
+    const uint32_t food = hl < H ? S[(size_t)hl * N] : 0u;
     uint32_t pt = 0;
-    if (lane < 4) pt = S[(size_t)PMX_W_AGENT_A(H, lane) * N];
-    else if (lane < 8) pt = S[(size_t)PMX_W_CAPS(H, (lane - 4) >> 1) * N];
+    if (hl < 4) pt = S[(size_t)PMX_W_AGENT_A(H, hl) * N];
+    else if (hl < 8) pt = S[(size_t)PMX_W_CAPS(H, (hl - 4) >> 1) * N];
     const uint32_t a_self = S[(size_t)PMX_W_AGENT_A(H, agent) * N];
     const uint32_t b_self = S[(size_t)PMX_W_AGENT_B(H, agent) * N];
-    uint32_t a_mate = 0, b_mate = 0;                          // the second learner after ITS sub-step (merged slot only)
-    if (merged) {
-        const uint32_t *S2 = p.snap[second] + env;
-        a_mate = S2[(size_t)PMX_W_AGENT_A(H, second) * N];
-        b_mate = S2[(size_t)PMX_W_AGENT_B(H, second) * N];
-    }
     const int n_words = (8 * HW + 31) >> 5;
     const int wall_words = (HW + 31) >> 5;
-    for (int k = lane; k < n_words + 1; k += 64) T[k] = (!flip && k < wall_words) ? L->wall_stream[k] : 0u;
+    for (int k = hl; k < n_words + 1; k += 32) T[k] = (!flip && k < wall_words) ? L->wall_stream[k] : 0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (lane < H) {
-        if (flip) stream_or_row(T, (uint32_t)(lane * W), flip_row(L->walls[lane], W, true), W);
+    if (hl < H) {
+        if (flip) stream_or_row(T, (uint32_t)(hl * W), flip_row(L->walls[hl], W, true), W);
         const uint32_t blue = flip_row(food & L->hi_mask, W, flip), red = flip_row(food & L->lo_mask, W, flip);
-        stream_or_row(T, (uint32_t)(((flip ? 7 : 6) * H + lane) * W), blue, W);     // plane 6: food with x >= int(W/2); swapped by the flip
-        stream_or_row(T, (uint32_t)(((flip ? 6 : 7) * H + lane) * W), red, W);
+        stream_or_row(T, (uint32_t)(((flip ? 7 : 6) * H + hl) * W), blue, W);
+        stream_or_row(T, (uint32_t)(((flip ? 6 : 7) * H + hl) * W), red, W);
     }
-    if (lane < 4) {
+    uint32_t pt_off = 0;                                      // lanes 0-3 of each half: that agent's bit offset in the stream
+    if (hl < 4) {
         const int x0 = pt & 0xFF, y = (pt >> 8) & 0xFF, x = flip ? W - 1 - x0 : x0;
-        const int plane = lane == agent ? 1 : (((lane ^ agent) == 2) ? 4 : 5);
-        if (!(merged && plane == 4)) {                                               // merge_obs_for_critic clears plane 4
-            const uint32_t off = (uint32_t)((plane * H + y) * W + x);
-            atomicOr(&T[off >> 5], 1u << (off & 31));
-        }
-    } else if (lane < 8) {
-        const uint32_t cxy = (pt >> (16 * ((lane - 4) & 1))) & 0xFFFFu;
+        const int plane = hl == agent ? 1 : (((hl ^ agent) == 2) ? 4 : 5);
+        pt_off = (uint32_t)((plane * H + y) * W + x);
+        atomicOr(&T[pt_off >> 5], 1u << (pt_off & 31));
+    } else if (hl < 8) {
+        const uint32_t cxy = (pt >> (16 * ((hl - 4) & 1))) & 0xFFFFu;
         if (cxy != 0xFFFFu) {
             const int x0 = cxy & 0xFF, y = cxy >> 8, x = flip ? W - 1 - x0 : x0;
             const int plane0 = (2 * x0 > W) ? 2 : 3;
@@ -1218,54 +1224,77 @@ __global__ __launch_bounds__(PMX_BLOCK) void pmx_emit_team_kernel(PmxEmitParams 
             atomicOr(&T[off >> 5], 1u << (off & 31));
         }
     }
-    uint32_t carry = (b_self >> 8) & 0xFFF;
     const int sx = (int)(a_self & 0xFF);
-    const int fself = (H + (int)((a_self >> 8) & 0xFF)) * W + (flip ? W - 1 - sx : sx);
-    int fmate = -1;
-    uint32_t carry_mate = 0;
-    if (merged) {
-        const int mx = (int)(a_mate & 0xFF);
-        fmate = (H + (int)((a_mate >> 8) & 0xFF)) * W + (flip ? W - 1 - mx : mx);
-        carry_mate = (b_mate >> 8) & 0xFFF;
-        if (fmate == fself) {                                  // both learners on one cell: max(1 + carry, 1 + carry')
-            carry = carry > carry_mate ? carry : carry_mate;
-            fmate = -1;
-        } else if (lane == 0) {
-            atomicOr(&T[(uint32_t)fmate >> 5], 1u << ((uint32_t)fmate & 31));
-        }
+    const int fself_v = (H + (int)((a_self >> 8) & 0xFF)) * W + (flip ? W - 1 - sx : sx);
+    const int fself0 = __builtin_amdgcn_readlane(fself_v, 0), fself1 = __builtin_amdgcn_readlane(fself_v, 32);
+    const uint32_t carry0 = (__builtin_amdgcn_readlane((int)b_self, 0) >> 8) & 0xFFF;
+    const uint32_t carry1 = (__builtin_amdgcn_readlane((int)b_self, 32) >> 8) & 0xFFF;
+    // merged slot (merge_obs_for_critic): plane 4 of the first learner's stream cleared, the second learner -- where ITS OWN
+    // snapshot has it -- added to plane 1; both learners on one cell: max(1 + carry, 1 + carry')
+    const int f_ally = second == 2 ? __builtin_amdgcn_readlane((int)pt_off, 2) : __builtin_amdgcn_readlane((int)pt_off, 3);
+    int fmate = fself1;
+    uint32_t carry_m = carry0;
+    if (fmate == fself0) {
+        carry_m = carry0 > carry1 ? carry0 : carry1;
+        fmate = -1;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
     const int n_vec = 8 * HW / VEC;
-    uint4 *out = merged ? reinterpret_cast<uint4 *>(p.merged) + (size_t)env * n_vec
-                        : reinterpret_cast<uint4 *>(p.team_obs) + ((size_t)env * 2 + slot) * n_vec;
-    for (int k = lane; k < n_vec; k += 64) {
-        const uint32_t e0 = (uint32_t)k * VEC;
-        const uint32_t bits = T[e0 >> 5] >> (e0 & 31);
-        uint4 v;
-        if (DT == 0) v = *reinterpret_cast<const uint4 *>(&lut[(bits & 15u) * 4]);
-        else if (DT == 1) v = *reinterpret_cast<const uint4 *>(&lut[(bits & 255u) * 4]);
-        else {
-            const uint2 lo = *reinterpret_cast<const uint2 *>(&lut[(bits & 255u) * 2]);
-            const uint2 hi = *reinterpret_cast<const uint2 *>(&lut[((bits >> 8) & 255u) * 2]);
-            v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    const int total = (p.merged ? 3 : 2) * n_vec;
+    uint4 *out_team = reinterpret_cast<uint4 *>(p.team_obs) + (size_t)env * 2 * n_vec;            // slots 0, 1 are contiguous
+    uint4 *out_merged = reinterpret_cast<uint4 *>(p.merged) + (size_t)env * n_vec - 2 * n_vec;   // indexed by kk >= 2 n_vec
+    const uint32_t *T0 = tab[wave][0], *T1 = tab[wave][1];
+    for (int base = 0; base < total; base += 64 * U) {
+        uint32_t bits[U], e0s[U];
+        int sl[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = base + 64 * u + lane;
+            const int s = (kk >= n_vec) + (kk >= 2 * n_vec);
+            const bool ok = kk < total;
+            sl[u] = ok ? s : 0;
+            e0s[u] = ok ? (uint32_t)(kk - s * n_vec) * VEC : 0u;
+            bits[u] = (sl[u] == 1 ? T1 : T0)[e0s[u] >> 5] >> (e0s[u] & 31);
+            if (sl[u] == 2) {
+                const uint32_t d4 = (uint32_t)(f_ally - (int)e0s[u]);
+                if (d4 < (uint32_t)VEC) bits[u] &= ~(1u << d4);
+                const uint32_t d2 = (uint32_t)(fmate - (int)e0s[u]);
+                if (fmate >= 0 && d2 < (uint32_t)VEC) bits[u] |= 1u << d2;
+            }
         }
-        const uint32_t d = (uint32_t)(fself - (int)e0);
-        if (d < (uint32_t)VEC) patch_self<DT>(v, (int)d, carry);
-        if (fmate >= 0) {
-            const uint32_t d2 = (uint32_t)(fmate - (int)e0);
-            if (d2 < (uint32_t)VEC) patch_self<DT>(v, (int)d2, carry_mate);
+        uint4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (DT == 0) v[u] = *reinterpret_cast<const uint4 *>(&lut[(bits[u] & 15u) * 4]);
+            else if (DT == 1) v[u] = *reinterpret_cast<const uint4 *>(&lut[(bits[u] & 255u) * 4]);
+            else {
+                const uint2 lo = *reinterpret_cast<const uint2 *>(&lut[(bits[u] & 255u) * 2]);
+                const uint2 hi = *reinterpret_cast<const uint2 *>(&lut[((bits[u] >> 8) & 255u) * 2]);
+                v[u] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
         }
-        out[k] = v;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = base + 64 * u + lane;
+            const int fs = sl[u] == 1 ? fself1 : fself0;
+            const uint32_t cr = sl[u] == 0 ? carry0 : (sl[u] == 1 ? carry1 : carry_m);
+            const uint32_t d = (uint32_t)(fs - (int)e0s[u]);
+            if (d < (uint32_t)VEC) patch_self<DT>(v[u], (int)d, cr);
+            if (sl[u] == 2 && fmate >= 0) {
+                const uint32_t d2 = (uint32_t)(fmate - (int)e0s[u]);
+                if (d2 < (uint32_t)VEC) patch_self<DT>(v[u], (int)d2, carry1);
+            }
+            if (kk < total) (sl[u] == 2 ? out_merged : out_team)[kk] = v[u];
+        }
     }
 }
 
 // ev0 / ev1 (both or neither): start / stop events of this very dispatch, as in pmx_launch_expand
 extern "C" hipError_t pmx_launch_emit_team(const PmxEmitParams *p, int dtype, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1)
 {
-    const long waves = (long)p->N * (p->merged ? 3 : 2);
-    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    const unsigned blocks = (unsigned)(((long)p->N + 3) / 4);    // one wave per env
 #define PMX_EMIT(DT)                                                                                                          \
     do {                                                                                                                      \
         if (ev0) hipExtLaunchKernelGGL(pmx_emit_team_kernel<DT>, dim3(blocks), dim3(PMX_BLOCK), 0, st, ev0, ev1, 0, *p);       \
