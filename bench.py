@@ -141,7 +141,7 @@ def emit_team_probe(lay, n_envs, length, dev, rank, actions, launches=ROOFLINE_M
             "avg_launch_us": avg_s * 1e6, "launches": tot_n, "segment_avg_us_min_max": [min(seg_us), max(seg_us)],
             "slots": n_slots, "checksum": checksum,
             "note": "3 slots (learner, learner, merged) x 8 planes x H x W bytes per env-tick; the product's observation path "
-                    "(VecMAPPOTrainer.rollout), one launch per tick"}
+                    "(VecMAPPOTrainer.rollout), one launch per tick, one wavefront per env"}
 
 
 def e2e_probe(layout, dev, rank, world, dist, n_envs, horizon, minibatch, use_graph, algorithm="mappo", rehearse_dp=False, autocast=True):
