@@ -647,6 +647,50 @@ def test_soak_four_episodes_mixed_controllers_vs_oracle(layname):
     env.close()
 
 
+def _emit_check(env, team, merged, raw, tag):
+    """pmx_emit_team_obs of the env's current snapshots == canonicalize_obs / merge_obs_for_critic of the planes `raw`, both colours"""
+    from pmx import trainer
+    for red in (False, True):
+        ids = [0, 2] if red else [1, 3]
+        want = raw[:, ids].float()
+        if red:
+            want = trainer.canonicalize_obs(want)
+        want_m = trainer.merge_obs(want[:, 0].contiguous(), want[:, 1].contiguous())
+        team.fill_(9); merged.fill_(9)
+        env.emit_team_obs(red, team, merged)
+        assert torch.equal(team.float(), want), (tag, red)
+        assert torch.equal(merged.float(), want_m), (tag, red)
+
+
+@pytest.mark.parametrize("case", ["ragged131", "remapped256", "mazes256"])
+def test_emit_team_obs_env_counts_and_per_env_layouts(case):
+    """The one-wave-per-env kernel's block order depends on the env count (multiples of 128 are dealt to the XCDs in groups of
+    the 16 envs that share a line of snapshot words; other counts are not, and a count that is no multiple of 4 leaves waves of the
+    last block idle), and with per-env layouts every wave reads its own layout record: byte planes, both colours, 40 ticks."""
+    import pmx
+    if case == "mazes256":
+        from pmx import maze_generator
+        N = 256
+        lay = [pmx.Layout.from_text(maze_generator.generate_maze(seed)) for seed in range(1, N + 1)]
+    else:
+        N = 131 if case == "ragged131" else 256
+        lay = "smallCapture"
+    env = pmx.PmxVecEnv(lay, N, length=25, auto_reset=True, obs_dtype="uint8", seed=3)
+    H, W = env.layout.height, env.layout.width
+    team = torch.empty((N, 2, 8, H, W), dtype=torch.uint8, device="cuda")
+    merged = torch.empty((N, 8, H, W), dtype=torch.uint8, device="cuda")
+    guard = torch.full((4096,), 9, dtype=torch.uint8, device="cuda")     # allocated right behind: a store past the end would land here
+    obs, _ = env.reset()
+    _emit_check(env, team, merged, obs.clone(), "reset")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for t in range(40):
+        a = torch.randint(0, 5, (N, 4), generator=g, device="cuda", dtype=torch.int8)
+        obs, _, _, _ = env.step(a)
+        _emit_check(env, team, merged, obs.clone(), t)
+    assert int(guard.min()) == 9 and int(guard.max()) == 9
+    env.close()
+
+
 @pytest.mark.parametrize("layout", ["smallCapture", "tinyCapture", "bloxCapture"])
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16", "uint8"])
 def test_emit_team_obs_equals_canonicalize_and_merge_of_the_tick_observations(layout, dtype):
