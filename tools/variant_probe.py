@@ -8,13 +8,13 @@ import pmx
 
 VARIANTS = [
     ("default", {}),
-    ("cap40000", {"expand_lds_pad": 40000}),
-    ("cap20000", {"expand_lds_pad": 20000}),
     ("cap12000", {"expand_lds_pad": 12000}),
-    ("wave_per_env", {"expand_wave_per_env": 1, "expand_nt": 0}),
-    ("wave_per_env_nt", {"expand_wave_per_env": 1, "expand_nt": 1}),
-    ("nt", {"expand_nt": 1, "expand_lds_pad": 0}),
+    ("nt_cap24000", {"expand_nt": 1, "expand_lds_pad": 24000}),
+    ("nt_cap30000", {"expand_nt": 1, "expand_lds_pad": 30000}),
     ("nt_cap40000", {"expand_nt": 1, "expand_lds_pad": 40000}),
+    ("nt_cap50000", {"expand_nt": 1, "expand_lds_pad": 50000}),
+    ("nt_cap70000", {"expand_nt": 1, "expand_lds_pad": 70000}),
+    ("wave_per_env_nt_cap40000", {"expand_wave_per_env": 1, "expand_nt": 1, "expand_lds_pad": 40000}),
 ]
 KEYS = ["expand_lds_pad", "expand_wave_per_env", "expand_nt"]
 
