@@ -9,7 +9,7 @@ as small .npz/.json data files.  Those files are what pins the oracle
 
 Usage (from anywhere):
     PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python tests/golden/make_golden.py [section ...]
-sections: traj scen dist maze gae ppo ppo_init shaping bots   (default: all)
+sections: traj scen dist maze gae ppo ppo_init ppo_init_blox shaping bots   (default: all)
 
 Fixture catalogue:
   G1 traj_*.npz      gymPacMan_parallel_env(self_play=True) trajectories, per sub-step state
@@ -20,6 +20,7 @@ Fixture catalogue:
   G6 gae.npz         pacman_mappo_resnet.compute_gae
   G7 ppo.npz         MAPPOAgent forward / PPO loss / grad-norm / Adam step with closed-form weights
   G7b ppo_init.npz   the same on the reference's own (seeded) orthogonal initialisation, paired rows: pins the bf16 production path
+  G7c ppo_init_blox.npz  G7b on bloxCapture (20 x 20, the layout the reference trains on): pins the 28-tile tower and 416-token attention kernels
   G8 shaping.npz     compute_heuristic_shaping / canonicalize_obs / merge_obs_for_critic
   G9 bots_*.json     baselineTeam / randomTeam action traces under random.seed(k)
 """
@@ -735,21 +736,21 @@ def sharpen_init(model):
                 p.add_(0.1 * torch.sin(0.37 * torch.arange(p.numel(), dtype=torch.float64) + 1.3 * j).to(p.dtype))
 
 
-def section_ppo_init():
-    """G7b: the reference's MAPPOAgent with ITS OWN initialisation (orthogonal weights, pacman_mappo_resnet.py:149-158) under a
+def section_ppo_init(traj="traj_small_hunter.npz", out_name="ppo_init.npz", label="G7b", P=32):
+    """G7b / G7c (the same on bloxCapture, 20 x 20: the board of the 28-tile tower kernels and the 416-token attention): the reference's MAPPOAgent with ITS OWN initialisation (orthogonal weights, pacman_mappo_resnet.py:149-158) under a
     fixed torch seed -- the seed and per-tensor checksums are stored, not the 2.6 M weights -- on 32 env-ticks x 2 learners of a
     real trajectory (paired rows 2k, 2k + 1 share merged input k), once as initialised ("init") and once after sharpen_init
     ("sharp": logits and values of O(1)).  Unlike the closed-form sine weights of G7, these are the weights training starts
     from, so a bf16 evaluation of this fixture is representative of the production path."""
-    print("G7b PPO losses, reference initialisation")
+    print(f"{label} PPO losses, reference initialisation ({traj})")
     with contextlib.redirect_stdout(io.StringIO()):
         import pacman_mappo_resnet as M
     seed = 20260
     torch.set_num_threads(1)
-    z = np.load(os.path.join(OUT, "traj_small_hunter.npz"))
+    z = np.load(os.path.join(OUT, traj))
     obs_all = z["obs"]  # [T,4,8,H,W] u8
-    P = 32
     idx = np.arange(7, 7 + P * 9, 9)
+    assert idx[-1] < obs_all.shape[0], (idx[-1], obs_all.shape)
     ob1 = torch.tensor(obs_all[idx, 1].astype(np.float32))
     ob3 = torch.tensor(obs_all[idx, 3].astype(np.float32))
     obs = torch.stack([ob1, ob3], dim=1).reshape((2 * P,) + tuple(ob1.shape[1:]))              # rows 2k, 2k+1 = the two blue learners
@@ -796,8 +797,12 @@ def section_ppo_init():
         weights="torch.manual_seed(seed); MAPPOAgent(obs_shape, 5, 2): the reference's orthogonal initialisation; 'sharp' = sharpen_init of it",
         param_names=names, torch_version=torch.__version__,
         source="pacman_mappo_resnet.MAPPOAgent.__init__/evaluate + PPO loss lines 577-590")).encode(), np.uint8)
-    np.savez_compressed(os.path.join(OUT, "ppo_init.npz"), **out)
-    print("  ppo_init.npz")
+    np.savez_compressed(os.path.join(OUT, out_name), **out)
+    print("  " + out_name)
+
+
+def section_ppo_init_blox():
+    section_ppo_init("traj_blox_hunter.npz", "ppo_init_blox.npz", "G7c")
 
 
 def section_shaping():
@@ -882,7 +887,7 @@ def section_bots():
 
 
 SECTIONS = dict(traj=section_traj, scen=section_scen, dist=section_dist, maze=section_maze, gae=section_gae,
-                ppo=section_ppo, ppo_init=section_ppo_init, shaping=section_shaping, bots=section_bots)
+                ppo=section_ppo, ppo_init=section_ppo_init, ppo_init_blox=section_ppo_init_blox, shaping=section_shaping, bots=section_bots)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)

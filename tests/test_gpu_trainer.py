@@ -427,18 +427,29 @@ BF16_BOUNDS = {
     "init": dict(logp=2e-3, values=4e-3, scalars=2e-2, grad_norm=6e-2),
     "sharp": dict(logp=4e-2, values=3e-2, scalars=3e-2, grad_norm=8e-2),
 }
+# Absolute slack of the scalar losses.  The policy-gradient term of these fixtures is a 1e-2 mean of 64 products of O(1): on the
+# sharpened 20 x 20 model (G7c) per-sample log-probability errors of up to 1.6e-2 move it by 1e-3 (measured: 9.6e-4, i.e. 9.5 % of
+# 0.0101, with vl and the total loss within 1 %), so the relative bound alone would test the fixture's cancellation, not the kernels.
+BF16_ABS_SLACK = {("small", "init"): 2e-4, ("small", "sharp"): 2e-4, ("blox", "init"): 2e-4, ("blox", "sharp"): 2e-3}
+# measured on one MI355X (uint8 and bf16 planes alike):           logp      values    pg rel    vl rel    loss rel  grad norm
+#   small init / sharp                                            1.4e-4    1.7e-3    7e-6      7e-5      1e-4      1.4e-4
+#                                                                 1.6e-2    1.3e-2    2.7e-2    8.7e-3    1.1e-2    6.3e-3
+#   blox  init / sharp                                            1.7e-4    1.4e-3    3.4e-4    1.5e-4    2.8e-4    4e-6
+#                                                                 1.6e-2    1.3e-2    9.5e-2    8.1e-3    5.0e-3    6.5e-3
 
 
+@pytest.mark.parametrize("board", ["small", "blox"])
 @pytest.mark.parametrize("tag", ["init", "sharp"])
-def test_bf16_autocast_loss_tracks_the_reference_fixture(tag):
+def test_bf16_autocast_loss_tracks_the_reference_fixture(tag, board):
     """The production path -- bf16 autocast on byte planes, fused actor tower, fused feed-forward / projection / LayerNorm
     kernels, hand-written attention, the one-launch loss, paired minibatch -- against numbers the REFERENCE computed in float32
-    on its own seeded initialisation (fixture G7b: the weights are reproduced from the seed, see test_mappo_cpu).  Bounds are
+    on its own seeded initialisation (fixtures G7b on smallCapture and G7c on bloxCapture -- the 28-tile tower kernels and the 416-token
+    attention; the weights are reproduced from the seed, see test_mappo_cpu).  Bounds are
     stated per quantity in BF16_BOUNDS: per-sample log-probabilities and values absolutely, the scalar losses, the mean entropy
     and the gradient norm relatively.  (BASELINE.json's 1e-4 is the float32 figure, held by the float32 tests.)"""
     from pmx import mappo
     from test_mappo_cpu import _init_batch, reference_init_model
-    d, meta, obs, merged, act, old_logp, adv, ret = _init_batch(tag)
+    d, meta, obs, merged, act, old_logp, adv, ret = _init_batch(tag, board)   # board "blox": fixture G7c, 20 x 20 (28-tile tower, 416-token attention)
     bd = BF16_BOUNDS[tag]
     model = reference_init_model(tag, tuple(obs.shape[1:]), meta["seed"]).cuda()
     c = lambda x: x.cuda()
@@ -456,7 +467,7 @@ def test_bf16_autocast_loss_tracks_the_reference_fixture(tag):
         assert dv <= bd["values"], ("values", float(dv))
         for k in ("pg", "vl", "loss"):
             ref = float(d[f"{tag}_{k}"])
-            assert abs(float(stats[k]) - ref) <= bd["scalars"] * abs(ref) + 2e-4, (k, float(stats[k]), ref)
+            assert abs(float(stats[k]) - ref) <= bd["scalars"] * abs(ref) + BF16_ABS_SLACK[(board, tag)], (k, float(stats[k]), ref)
         ref_e = float(np.mean(d[f"{tag}_entropy"]))
         assert abs(float(stats["entropy"]) - ref_e) <= bd["scalars"] * ref_e
         learner._backward_into_bucket(loss)          # (the heads' gradients arrive through their bf16 shadow copies)

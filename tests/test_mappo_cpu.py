@@ -90,20 +90,24 @@ def reference_init_model(tag, shape, seed):
     return model
 
 
-def _init_batch(tag):
-    d, meta = G.load("ppo_init.npz")
+INIT_FIXTURES = {"small": "ppo_init.npz", "blox": "ppo_init_blox.npz"}      # G7b (smallCapture), G7c (bloxCapture, 20 x 20)
+
+
+def _init_batch(tag, board="small"):
+    d, meta = G.load(INIT_FIXTURES[board])
     t = lambda k, dt=torch.float32: torch.tensor(d[k]).to(dt)
     return (d, meta, t("obs"), t("merged"), t(f"{tag}_act", torch.long), t(f"{tag}_old_logp"), t(f"{tag}_adv"), t(f"{tag}_ret"))
 
 
+@pytest.mark.parametrize("board", ["small", "blox"])
 @pytest.mark.parametrize("tag", ["init", "sharp"])
-def test_reference_initialisation_fixture_fp32(tag):
-    """G7b: the reference's own seeded initialisation is reproduced weight for weight (per-tensor sums), and the float32 model
+def test_reference_initialisation_fixture_fp32(tag, board):
+    """G7b / G7c (the same on the 20 x 20 board the reference trains on): the reference's own seeded initialisation is reproduced weight for weight (per-tensor sums), and the float32 model
     gives the reference's logits, values, log-probabilities, entropies, losses and per-tensor gradient norms within 1e-4 on
     the paired batch (merged input k serves rows 2k and 2k + 1)."""
     from pmx import mappo
     torch.set_num_threads(2)
-    d, meta, obs, merged, act, old_logp, adv, ret = _init_batch(tag)
+    d, meta, obs, merged, act, old_logp, adv, ret = _init_batch(tag, board)
     model = reference_init_model(tag, tuple(obs.shape[1:]), meta["seed"])
     assert [n for n, _ in model.named_parameters()] == meta["param_names"]
     # (the same draws; a LAPACK build or thread count that rounds the QR differently moves a sum in its 6th digit at most)
