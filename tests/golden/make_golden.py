@@ -9,7 +9,7 @@ as small .npz/.json data files.  Those files are what pins the oracle
 
 Usage (from anywhere):
     PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python tests/golden/make_golden.py [section ...]
-sections: traj scen dist maze gae ppo ppo_init ppo_init_blox shaping bots   (default: all)
+sections: traj scen dist maze gae ppo ppo_init ppo_init_blox ppo_init_tiny shaping bots   (default: all)
 
 Fixture catalogue:
   G1 traj_*.npz      gymPacMan_parallel_env(self_play=True) trajectories, per sub-step state
@@ -21,6 +21,7 @@ Fixture catalogue:
   G7 ppo.npz         MAPPOAgent forward / PPO loss / grad-norm / Adam step with closed-form weights
   G7b ppo_init.npz   the same on the reference's own (seeded) orthogonal initialisation, paired rows: pins the bf16 production path
   G7c ppo_init_blox.npz  G7b on bloxCapture (20 x 20, the layout the reference trains on): pins the 28-tile tower and 416-token attention kernels
+  G7d ppo_init_tiny.npz  G7b on tinyCapture (7 x 20, BASELINE configs[1]): the 10-tile tower kernels
   G8 shaping.npz     compute_heuristic_shaping / canonicalize_obs / merge_obs_for_critic
   G9 bots_*.json     baselineTeam / randomTeam action traces under random.seed(k)
 """
@@ -805,6 +806,10 @@ def section_ppo_init_blox():
     section_ppo_init("traj_blox_hunter.npz", "ppo_init_blox.npz", "G7c")
 
 
+def section_ppo_init_tiny():
+    section_ppo_init("traj_tiny_hunter.npz", "ppo_init_tiny.npz", "G7d")
+
+
 def section_shaping():
     print("G8 shaping / canonicalize / merge")
     with contextlib.redirect_stdout(io.StringIO()):
@@ -887,7 +892,7 @@ def section_bots():
 
 
 SECTIONS = dict(traj=section_traj, scen=section_scen, dist=section_dist, maze=section_maze, gae=section_gae,
-                ppo=section_ppo, ppo_init=section_ppo_init, ppo_init_blox=section_ppo_init_blox, shaping=section_shaping, bots=section_bots)
+                ppo=section_ppo, ppo_init=section_ppo_init, ppo_init_blox=section_ppo_init_blox, ppo_init_tiny=section_ppo_init_tiny, shaping=section_shaping, bots=section_bots)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)

@@ -90,7 +90,7 @@ def reference_init_model(tag, shape, seed):
     return model
 
 
-INIT_FIXTURES = {"small": "ppo_init.npz", "blox": "ppo_init_blox.npz"}      # G7b (smallCapture), G7c (bloxCapture, 20 x 20)
+INIT_FIXTURES = {"small": "ppo_init.npz", "blox": "ppo_init_blox.npz", "tiny": "ppo_init_tiny.npz"}   # G7b smallCapture, G7c bloxCapture (20 x 20), G7d tinyCapture
 
 
 def _init_batch(tag, board="small"):
@@ -99,7 +99,7 @@ def _init_batch(tag, board="small"):
     return (d, meta, t("obs"), t("merged"), t(f"{tag}_act", torch.long), t(f"{tag}_old_logp"), t(f"{tag}_adv"), t(f"{tag}_ret"))
 
 
-@pytest.mark.parametrize("board", ["small", "blox"])
+@pytest.mark.parametrize("board", ["small", "blox", "tiny"])
 @pytest.mark.parametrize("tag", ["init", "sharp"])
 def test_reference_initialisation_fixture_fp32(tag, board):
     """G7b / G7c (the same on the 20 x 20 board the reference trains on): the reference's own seeded initialisation is reproduced weight for weight (per-tensor sums), and the float32 model
