@@ -389,6 +389,11 @@ int pmx_ffn_backward(const void *x_dev, const void *dy_dev, const void *pack_dev
 int pmx_tok96_pack(const float *w, const float *b, void *pack_dev, void *stream);
 int pmx_tok96_forward(const void *a_dev, const void *pack_dev, void *y_dev, int64_t tokens, void *stream);
 int pmx_tok96_backward(const void *a_dev, const void *dy_dev, const void *pack_dev, void *da_dev, float *grad_dev, int64_t tokens, void *stream);
+/* pmx_tok96_backward with da = in_proj_weight^T dy + res: res_dev [tokens][32] bfloat16 (or NULL) is the gradient that reaches the same
+ * tokens through the residual connection of the encoder layer (nn.TransformerEncoderLayer: norm1(x + self_attn(x)), pacman_mappo_resnet.py:
+ * 138-141) -- autograd would add the two with a kernel of its own.  res_dev must not be da_dev. */
+int pmx_tok96_backward_res(const void *a_dev, const void *dy_dev, const void *pack_dev, const void *res_dev, void *da_dev, float *grad_dev,
+                           int64_t tokens, void *stream);
 int pmx_tok32ln_pack(const float *w, const float *b, const float *gamma, const float *beta, void *pack_dev, void *stream);
 int pmx_tok32ln_forward(const void *x_dev, const void *a_dev, const void *pack_dev, void *y_dev, int64_t tokens, float eps, void *stream);
 int pmx_tok32ln_backward(const void *x_dev, const void *a_dev, const void *dy_dev, const void *pack_dev, void *dx_dev, void *da_dev,

@@ -117,6 +117,7 @@ PROTOTYPES = [
     ("pmx_tok96_pack", C.c_int, [_VP, _VP, _VP, _VP]),
     ("pmx_tok96_forward", C.c_int, [_VP, _VP, _VP, C.c_int64, _VP]),
     ("pmx_tok96_backward", C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
+    ("pmx_tok96_backward_res", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
     ("pmx_tok32ln_pack", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     ("pmx_tok32ln_forward", C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_float, _VP]),
     ("pmx_tok32ln_backward", C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_float, _VP]),

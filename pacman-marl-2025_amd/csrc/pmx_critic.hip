@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256, 2) void pmx_tok_bwd_kernel(const uint4 *__rest
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             av[u] = fetch(a, pair, u, 4, g);
-            xv4[u] = LN ? fetch(x, pair, u, 4, g) : uint4{0, 0, 0, 0};
+            xv4[u] = (LN || x) ? fetch(x, pair, u, 4, g) : uint4{0, 0, 0, 0};    // !LN: x = a gradient to ADD to da (or null)
 #pragma unroll
             for (int q = 0; q < NP; ++q) dv[u][q] = fetch(dy, pair, u, 4 * NP, 4 * q + g);
         }
@@ -660,6 +660,13 @@ __global__ __launch_bounds__(256, 2) void pmx_tok_bwd_kernel(const uint4 *__rest
                 const float v[8] = {lo_f(dt[q].x), hi_f(dt[q].x), lo_f(dt[q].y), hi_f(dt[q].y), lo_f(dt[q].z), hi_f(dt[q].z), lo_f(dt[q].w), hi_f(dt[q].w)};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) db[q][j] += v[j];
+            }
+            if (!LN && x) {
+                // the residual branch's gradient of the same tokens (the encoder layer's input feeds the in-projection AND the residual
+                // add in front of norm1): summed here in float32 and rounded once, instead of by an add kernel of autograd's
+                const uint4 r = xv4[u];
+                e0[0] += lo_f(r.x), e0[1] += hi_f(r.x), e0[2] += lo_f(r.y), e0[3] += hi_f(r.y);
+                e1[0] += lo_f(r.z), e1[1] += hi_f(r.z), e1[2] += lo_f(r.w), e1[3] += hi_f(r.w);
             }
             const long tok = pair * 32 + 16 * u + p;
             if (tok < T) da[tok * 4 + g] = uint4{pack2(e0[0], e0[1]), pack2(e0[2], e0[3]), pack2(e1[0], e1[1]), pack2(e1[2], e1[3])};
@@ -896,6 +903,12 @@ extern "C" int pmx_tok96_forward(const void *a_dev, const void *pack_dev, void *
 extern "C" int pmx_tok96_backward(const void *a_dev, const void *dy_dev, const void *pack_dev, void *da_dev, float *grad_dev, int64_t tokens, void *stream)
 {
     return tok_backward<3, false>(a_dev, nullptr, dy_dev, pack_dev, da_dev, nullptr, grad_dev, tokens, 0.f, reinterpret_cast<hipStream_t>(stream));
+}
+extern "C" int pmx_tok96_backward_res(const void *a_dev, const void *dy_dev, const void *pack_dev, const void *res_dev, void *da_dev, float *grad_dev,
+                                      int64_t tokens, void *stream)
+{
+    if (res_dev && res_dev == da_dev) return PMX_ERR_INVALID;          // the operands are read through restrict pointers
+    return tok_backward<3, false>(a_dev, res_dev, dy_dev, pack_dev, da_dev, nullptr, grad_dev, tokens, 0.f, reinterpret_cast<hipStream_t>(stream));
 }
 extern "C" int pmx_tok32ln_pack(const float *w, const float *b, const float *gamma, const float *beta, void *pack_dev, void *stream)
 {

@@ -267,6 +267,46 @@ class _InProj96(torch.autograd.Function):
         return da, grad[:3072].view(96, 32).to(ctx.dtypes[0]), grad[3072:3168].to(ctx.dtypes[1]), None
 
 
+class _InProj96Res(torch.autograd.Function):
+    """_InProj96 that also hands its input back as a second output, `a_res`, for the layer's residual connection: the gradient of
+    the residual branch then arrives HERE, and pmx_tok96_backward_res adds it to W^T dy inside the kernel (float32, rounded once)
+    instead of autograd adding the two bfloat16 tensors with a launch of its own (one per encoder layer and optimizer step)."""
+
+    @staticmethod
+    def forward(ctx, a, w, b, pack=None):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        a = a.contiguous()
+        st = C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+        if pack is None:
+            pack = pack_in_proj(w, b)
+        y = torch.empty(a.shape[:-1] + (96,), dtype=torch.bfloat16, device=a.device)
+        _lib.check(lib.pmx_tok96_forward(a.data_ptr(), pack.data_ptr(), y.data_ptr(), a.numel() // 32, st), "pmx_tok96_forward")
+        ctx.save_for_backward(a, pack)
+        ctx.dtypes = (w.dtype, b.dtype)
+        return y, a.view_as(a)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        a, pack = ctx.saved_tensors
+        st = C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+        grad = torch.empty((1 + _lib.GRAD_PARTIAL_ROWS) * _lib.TOK96_GRAD_FLOATS, dtype=torch.float32, device=a.device)
+        if dy is None:                                  # only the residual output was used
+            grad.zero_()
+            return dres, grad[:3072].view(96, 32).to(ctx.dtypes[0]), grad[3072:3168].to(ctx.dtypes[1]), None
+        dy = dy.to(torch.bfloat16).contiguous()
+        res = None if dres is None else dres.to(torch.bfloat16).contiguous()
+        da = torch.empty_like(a)
+        with _row_sums_deferred(lib, grad, _lib.TOK96_GRAD_FLOATS, all(dt == torch.float32 for dt in ctx.dtypes)):
+            _lib.check(lib.pmx_tok96_backward_res(a.data_ptr(), dy.data_ptr(), pack.data_ptr(), None if res is None else res.data_ptr(),
+                                                  da.data_ptr(), grad.data_ptr(), a.numel() // 32, st), "pmx_tok96_backward_res")
+        return da, grad[:3072].view(96, 32).to(ctx.dtypes[0]), grad[3072:3168].to(ctx.dtypes[1]), None
+
+
 class _OutProjAddLN(torch.autograd.Function):
     """LayerNorm(x + out_proj.weight a + out_proj.bias) on [..., 32] bfloat16 tokens (pmx_tok32ln_forward / _backward)."""
 
@@ -313,6 +353,13 @@ def in_proj96(x, mha, pack=None):
     if _fused_tokens_ok(x, mha.in_proj_weight) and tuple(mha.in_proj_weight.shape) == (96, 32):
         return _InProj96.apply(x, mha.in_proj_weight, mha.in_proj_bias, pack)
     return token_linear(x, mha.in_proj_weight, mha.in_proj_bias)
+
+
+def in_proj96_res(x, mha, pack=None):
+    """-> (qkv, x_res): x_res is x, to be used for the layer's residual connection (see _InProj96Res)."""
+    if _fused_tokens_ok(x, mha.in_proj_weight) and tuple(mha.in_proj_weight.shape) == (96, 32):
+        return _InProj96Res.apply(x, mha.in_proj_weight, mha.in_proj_bias, pack)
+    return token_linear(x, mha.in_proj_weight, mha.in_proj_bias), x
 
 
 def out_proj_add_layer_norm(x, a, proj, ln, pack=None):
@@ -593,12 +640,17 @@ class CriticEncoderLayer(nn.TransformerEncoderLayer):
                 pack_out_proj(mha.out_proj.weight, mha.out_proj.bias, self.norm1.weight, self.norm1.bias),
                 pack_ffn(self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, self.norm2.weight, self.norm2.bias))
 
+    fold_residual_gradient = True   # development switch: False = autograd adds the in-projection's and the residual's gradients itself
+
     def forward_batch_major(self, x, packs=None):
         """The same layer on x [B, S, 32] bfloat16 (tokens of a sample contiguous: the memory order of a channels-last
         convolution output), hand-written kernels only; the caller has checked fused_ok.  packs: this layer's packs() made ahead."""
         mha = self.self_attn
         p_in, p_out, p_ffn = packs if packs is not None else (None, None, None)
-        qkv = in_proj96(x, mha, p_in)
+        if torch.is_grad_enabled() and self.fold_residual_gradient:
+            qkv, x = in_proj96_res(x, mha, p_in)      # the residual branch's gradient is added inside the in-projection's backward kernel
+        else:
+            qkv = in_proj96(x, mha, p_in)
         a = attention8(qkv, True) if torch.is_grad_enabled() else attention8_forward(qkv, batch_major=True)
         x = out_proj_add_layer_norm(x, a, mha.out_proj, self.norm1, p_out)
         return ffn_layer_norm(x, self.linear1, self.linear2, self.norm2, p_ffn)

@@ -657,6 +657,72 @@ def test_batch_major_critic_matches_sequence_major_critic():
         assert rel <= 5e-2, (n, rel)
 
 
+@pytest.mark.parametrize("hw", [(11, 14), (20, 20)])
+def test_residual_gradient_folded_into_the_in_projection_backward(hw):
+    """CriticEncoderLayer.fold_residual_gradient: the layer input's gradient = W_in^T dqkv + (gradient of the residual branch), summed
+    inside pmx_tok96_backward_res in float32, against autograd's own bfloat16 add of the two (the switch off).  Same kernels
+    otherwise, so values are identical and every gradient agrees to one bfloat16 rounding of the layer-input gradients."""
+    from pmx import mappo
+    torch.manual_seed(5)
+    H, W = hw
+    m = mappo.MAPPOAgent((8, H, W)).cuda()
+    merged = (torch.rand(70, 8, H, W, device="cuda") < 0.2).to(torch.uint8)
+    res = {}
+    for fold in (False, True):
+        for layer in m.critic_transformer.layers:
+            layer.fold_residual_gradient = fold
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            v = m.value(merged).float()
+        (v * torch.linspace(-1, 1, v.numel(), device="cuda")).sum().backward()
+        res[fold] = (v.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    v0, g0 = res[False]
+    v1, g1 = res[True]
+    assert torch.equal(v0, v1)
+    assert g0.keys() == g1.keys() and any(n.startswith("critic_projector") for n in g0)
+    worst = 0.0
+    for n in g0:
+        rel = float((g0[n] - g1[n]).norm() / (g0[n].norm() + 1e-12))
+        worst = max(worst, rel)
+        assert rel <= 1e-2, (n, rel)
+
+
+def test_tok96_backward_res_adds_the_residual_gradient():
+    """pmx_tok96_backward_res against torch: da = dy W + res in float32 rounded once; parameter gradients unchanged by res; res = NULL
+    is pmx_tok96_backward."""
+    import ctypes as C
+    from pmx import _lib, mappo
+    lib = _lib.load()
+    torch.manual_seed(2)
+    T = 1000                                            # not a multiple of 32: ragged last pair
+    a = torch.randn(T, 32, device="cuda").to(torch.bfloat16)
+    dy = torch.randn(T, 96, device="cuda").to(torch.bfloat16)
+    res = torch.randn(T, 32, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(96, 32, device="cuda") * 0.2)
+    b = torch.randn(96, device="cuda") * 0.1
+    pack = mappo.pack_in_proj(w, b)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = {}
+    for tag, r in (("none", None), ("res", res)):
+        da = torch.full_like(a, 7.0)
+        grad = torch.zeros((1 + _lib.GRAD_PARTIAL_ROWS) * _lib.TOK96_GRAD_FLOATS, dtype=torch.float32, device="cuda")
+        _lib.check(lib.pmx_tok96_backward_res(a.data_ptr(), dy.data_ptr(), pack.data_ptr(), None if r is None else r.data_ptr(), da.data_ptr(),
+                                              grad.data_ptr(), T, st), "pmx_tok96_backward_res")
+        outs[tag] = (da.float(), grad[:_lib.TOK96_GRAD_FLOATS].clone())
+    da0 = torch.full_like(a, 7.0)
+    grad0 = torch.zeros_like(grad)
+    _lib.check(lib.pmx_tok96_backward(a.data_ptr(), dy.data_ptr(), pack.data_ptr(), da0.data_ptr(), grad0.data_ptr(), T, st), "pmx_tok96_backward")
+    assert torch.equal(outs["none"][0], da0.float()) and torch.equal(outs["none"][1], grad0[:_lib.TOK96_GRAD_FLOATS])
+    assert torch.equal(outs["res"][1], outs["none"][1])                       # the parameter gradients do not see res
+    want = dy.float() @ w.to(torch.bfloat16).float() + res.float()
+    err = (outs["res"][0] - want).abs().max() / want.abs().max()
+    assert float(err) <= 1e-2, float(err)
+    # the sum is rounded ONCE: closer to the float32 sum than bf16(bf16(dy W) + res) is allowed to be
+    twice = (outs["none"][0].to(torch.bfloat16) + res).float()
+    assert float((outs["res"][0] - want).abs().mean()) <= float((twice - want).abs().mean()) + 1e-6
+    assert lib.pmx_tok96_backward_res(a.data_ptr(), dy.data_ptr(), pack.data_ptr(), a.data_ptr(), a.data_ptr(), grad.data_ptr(), T, st) != 0   # res == da refused
+
+
 @pytest.mark.parametrize("B,paired,dtype", [(64, False, torch.float32), (1024, True, torch.float32), (4099 * 2, True, torch.float32),
                                             (1024, True, torch.bfloat16), (3, False, torch.float32)])
 def test_fused_ppo_loss_matches_the_torch_objective(B, paired, dtype):
