@@ -12,7 +12,10 @@ collective); the timed region is bracketed by barrier + synchronize and the repo
 The JSON line also carries
   roofline      the observation-expansion kernel (>95 % of the bytes): algorithmic bytes per launch / its average
                 duration from start/stop HIP events attached to each dispatch on the launch stream (pmx_profile_begin/end) vs the 8 TB/s HBM peak
+  roofline_emit_team  the same for pmx_emit_team_obs on byte planes, the observation kernel the training loop runs
   cpu_baseline  the CPU oracle (a port of the reference's tick, oracle/pmx_oracle.c) on one host core, bounded sample
+  ppo, ppo_config5  end-to-end MAPPO (rollout + GAE + 3 PPO epochs) on the workload at 512- and 16 384-sample minibatches, the
+                one-rank RCCL rehearsal of the data-parallel step, and BASELINE config 5's per-GPU shard (MAPPO and IPPO)
 """
 import argparse
 import json
